@@ -1,0 +1,179 @@
+"""Pin the CPU oracle (oracle/cpu_ref.py) against golden vectors produced by importing
+the reference itself (tests/golden/gen_golden.py).  CPU only; bit-exact for fp32."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as O
+from tests.conftest import load_golden
+from tests.golden_cfg import TINY, cfg_checksum
+
+g1 = load_golden("g1_ops.npz")
+
+
+def eq(a, b):
+    np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.mark.parametrize("tag", ["m1", "m16", "m128", "odd"])
+def test_matmul(tag):
+    eq(O.matmul(g1[f"matmul_{tag}_a"], g1[f"matmul_{tag}_b"]), g1[f"matmul_{tag}_c"])
+
+
+def test_transpose():
+    eq(O.transpose(g1["transpose_in"]), g1["transpose_out"])
+
+
+def test_norms():
+    x, g, b = g1["norm_x"], g1["norm_g"], g1["norm_b"]
+    eq(O.rmsnorm(x, g, 1e-6), g1["rmsnorm_1e6"])
+    eq(O.rmsnorm(x, g, 1e-5), g1["rmsnorm_1e5"])
+    eq(O.layernorm(x, g, b, 1e-5), g1["layernorm_1e5"])
+
+
+def test_activations_and_elementwise():
+    x = g1["act_x"]
+    eq(O.silu(x), g1["silu"])
+    eq(O.gelu(x), g1["gelu"])
+    eq(O.add(x, x[::-1].copy()), g1["add"])
+    eq(O.mul(x, x[::-1].copy()), g1["mul"])
+
+
+def test_rope_table_and_rotation():
+    cos, sin = O.precompute_freqs_cis(128, 64, 1e6)
+    eq(cos.astype(np.float32), g1["rope_cos_tab"])
+    eq(sin.astype(np.float32), g1["rope_sin_tab"])
+    pos = g1["rope_pos"]
+    q, k = O.rope(g1["rope_q"], g1["rope_k"], cos[pos].astype(np.float32), sin[pos].astype(np.float32))
+    eq(q, g1["rope_q_out"])
+    eq(k, g1["rope_k_out"])
+
+
+@pytest.mark.parametrize("tag", ["off", "sq", "dec"])
+def test_sdpa(tag):
+    eq(O.sdpa_causal(g1[f"sdpa_{tag}_q"], g1[f"sdpa_{tag}_k"], g1[f"sdpa_{tag}_v"]), g1[f"sdpa_{tag}_o"])
+
+
+def test_sdpa_explicit_scale():
+    eq(O.sdpa_causal(g1["sdpa_scale_q"], g1["sdpa_scale_k"], g1["sdpa_scale_v"], 0.25), g1["sdpa_scale_o"])
+
+
+def test_sdpa_fixed_cache_equals_sliced_sdpa():
+    """kernel-defined fixed-cache SDPA == reference SDPA on the valid prefix (expanded and GQA caches)."""
+    q, k, v = g1["sdpa_dec_q"], g1["sdpa_dec_k"], g1["sdpa_dec_v"]
+    kc = np.zeros((4, 64, 128), np.float32)
+    vc = np.full((4, 64, 128), 7.0, np.float32)
+    kc[:, :37], vc[:, :37] = k, v
+    eq(O.sdpa_causal_fixed_cache(q, kc, vc, 37), g1["sdpa_dec_o"])
+    # un-expanded cache (2 kv heads feeding 4 q heads)
+    k2, v2 = k[::2], v[::2]
+    ref = O.sdpa_causal(q, np.repeat(k2, 2, axis=0), np.repeat(v2, 2, axis=0))
+    kc2 = np.zeros((2, 64, 128), np.float32)
+    vc2 = np.zeros((2, 64, 128), np.float32)
+    kc2[:, :37], vc2[:, :37] = k2, v2
+    eq(O.sdpa_causal_fixed_cache(q, kc2, vc2, 37), ref)
+
+
+def test_shuffles():
+    t = g1["shuffle_in"]
+    eq(O.repeat_interleave_axis1(t, 3), g1["repeat_interleave_3"])
+    eq(O.transpose_3d_021(t), g1["transpose_3d_021"])
+    eq(O.concat_axis0(t, t[:2].copy()), g1["concat_axis0"])
+
+
+def test_bf16_round_trip():
+    v = g1["bf16_in"]
+    eq(O.f32_to_bf16_bits(v), g1["bf16_bits"])
+    eq(O.bf16_bits_to_f32(g1["bf16_bits"]), g1["bf16_back"])
+
+
+def test_sampler():
+    lg = g1["sample_logits"]
+    eq([O.sample_token(r, 0.0, 0, 1.0) for r in lg], g1["sample_t0"])
+    eq([O.sample_token(r, 0.0, 50, 0.9) for r in lg], g1["sample_t0_k50_p09"])
+    assert g1["sample_t0"][3] == 100  # exact tie -> lowest index
+    eq([O.argmax_lowest_index(r) for r in lg], g1["sample_t0"])
+
+
+def test_fp8_table_and_block_dequant():
+    g2 = load_golden("g2_fp8.npz")
+    deq = O.dequantize_fp8_e4m3_block(g2["codes"], g2["scale_bits"])
+    eq(deq, g2["deq"])
+    y = O.matmul(g2["x"], O.transpose(deq.astype(np.float32)))
+    eq(y, g2["y"])
+    t = O.fp8_e4m3_table()
+    assert np.isnan(t[0x7F]) and np.isnan(t[0xFF]) and t[0x7E] == 448.0 and t[0x01] == 2.0**-9
+
+
+def test_fp8_quantiser_round_trip():
+    """The synthetic quantiser is the inverse of the reference dequantiser on exactly
+    representable inputs and never emits the NaN codes."""
+    rng = np.random.default_rng(0)
+    codes = np.array([c for c in range(256) if c not in (0x7F, 0xFF, 0x80)], np.uint8)
+    w = rng.choice(codes, size=(128, 256)).astype(np.uint8)
+    w[0, 0] = 0x7E  # make absmax hit 448 so scale is exactly s
+    w[0, 128] = 0x7E
+    s = O.f32_to_bf16_bits(np.full((1, 2), 0.0078125, np.float32))
+    deq = O.dequantize_fp8_e4m3_block(w, s)
+    c2, s2 = O.quantize_fp8_e4m3_block(deq)
+    eq(s2, s)
+    eq(O.dequantize_fp8_e4m3_block(c2, s2), deq)
+    assert not np.any((c2 == 0x7F) | (c2 == 0xFF))
+    x = rng.standard_normal((256, 256)).astype(np.float32) * 0.02
+    c3, s3 = O.quantize_fp8_e4m3_block(x)
+    assert not np.any((c3 == 0x7F) | (c3 == 0xFF))
+    err = np.abs(O.dequantize_fp8_e4m3_block(c3, s3) - x).max() / np.abs(x).max()
+    assert err < 0.04  # e4m3 has 3 mantissa bits: half-ulp relative error 2^-4 at most
+
+
+def test_tiny_qwen3_model_bit_exact():
+    g3 = load_golden("g3_tiny_qwen3.npz")
+    w = O.make_qwen3_weights(TINY, seed=int(g3["seed"]), bf16=True)
+    assert cfg_checksum(w) == float(g3["wsum"])
+    model = O.build_qwen3_ref(TINY, w, max_pos=128)
+    prompt = [int(t) for t in g3["prompt"]]
+    hidden, _ = model(prompt, use_cache=True)
+    eq(hidden, g3["prefill_hidden"])
+    eq(model.get_logits(hidden), g3["prefill_logits"])
+    tokens, step_logits = model.generate(prompt, max_new_tokens=10, temperature=0.0, top_k=0, top_p=1.0,
+                                         return_logits=True)
+    eq(tokens, g3["tokens"])
+    eq(np.stack(step_logits), g3["step_logits"])
+
+
+def test_full_width_qwen3_layer_bit_exact():
+    g5 = load_golden("g5_qwen3_layer.npz")
+    cfg = dict(O.QWEN3_0_6B, num_layers=1, vocab_size=64)
+    w = O.make_qwen3_weights(cfg, seed=int(g5["seed"]), bf16=True)
+    assert cfg_checksum(w) == float(g5["wsum"])
+    block = O.build_qwen3_ref(cfg, w, max_pos=64).blocks[0]
+    y, kv = block(g5["x"], [0, 1, 2, 3, 4, 5], None, True)
+    eq(y, g5["y"])
+    y1, kv1 = block(g5["x1"], [6], kv, True)
+    eq(y1, g5["y1"])
+    eq(kv1[0], g5["k"])
+    eq(kv1[1], g5["v"])
+
+
+def test_decode_step_equals_prefill_row():
+    """Equivalence used to pin the kernel-defined fixed-cache path: decoding token t with a
+    KV cache equals row t of a length-(t+1) prefill (up to fp32 summation order)."""
+    w = O.make_qwen3_weights(TINY, seed=3, bf16=True)
+    model = O.build_qwen3_ref(TINY, w, max_pos=64)
+    ids = [5, 9, 300, 77, 1000, 12]
+    full, _ = model(ids, use_cache=False)
+    h, past = model(ids[:-1], use_cache=True)
+    last, _ = model(ids[-1:], past_key_values=past, use_cache=True)
+    np.testing.assert_allclose(last[0], full[-1], rtol=2e-4, atol=2e-5)
+
+
+def test_gpt2_small_config1_tokens():
+    """BASELINE config 1: GPT-2-small random-init, 16-token greedy decode on the CPU path."""
+    g4 = load_golden("g4_gpt2_small.npz")
+    w = O.make_gpt2_weights(O.GPT2_SMALL, seed=int(g4["seed"]))
+    assert cfg_checksum(w) == float(g4["wsum"])
+    model = O.build_gpt2_ref(O.GPT2_SMALL, w)
+    ids = model.generate([int(t) for t in g4["prompt"]], max_new_tokens=16, temperature=0.0, top_k=0, top_p=1.0)
+    eq(ids, g4["tokens"])

@@ -1,0 +1,14 @@
+"""pygpukit_amd - MI355X (gfx950) native implementation of PyGPUkit's LLM-inference hot path.
+
+Same operator / model surface as the reference package `pygpukit` for that path (GPUArray, ops.*,
+llm.CausalTransformerModel and the decode strategies); every op runs a hand-written HIP kernel
+through the C ABI of libpgk_hip.so.  There is no CPU backend: importing works anywhere, using it
+without the library or without a GPU raises.
+"""
+
+__version__ = "0.1.0"
+
+from pygpukit_amd import core, ops  # noqa: F401
+from pygpukit_amd.core import (CudaEvent, CudaGraph, DataType, GPUArray, Stream, bfloat16, device_synchronize, empty,  # noqa: F401
+                              event_elapsed_ms, event_elapsed_us, float16, float32, float64, from_numpy, get_backend,
+                              has_native_module, int4, int8, int16, int32, int64, ones, uint8, zeros)

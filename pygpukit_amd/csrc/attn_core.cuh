@@ -1,0 +1,153 @@
+// Split-KV decode attention core (flash-decoding) for gfx950, shared by the op-level
+// sdpa_causal_fixed_cache (ops_attention.hip) and the fused decode step (engine.hip).
+//
+// One workgroup = 4 waves owns one KV head and one contiguous chunk of cached positions and
+// serves all G = Hq/Hkv query heads of that KV head from a single pass over K and V (the
+// reference stores the cache GQA-expanded and re-reads it per query head: K17/K10 in SURVEY.md).
+// K/V rows go straight from HBM to VGPRs, 16 bytes per lane: D/8 lanes cover one row, so one
+// wave-instruction fetches 64/(D/8) consecutive positions = 1 KiB contiguous.  Each lane-group keeps
+// its own online-softmax state (m, l, o[8]) per query head; groups and waves are merged once at
+// the end through LDS, and chunks are merged by a second tiny kernel (or by the consumer).
+#pragma once
+
+#include "pgk_device.cuh"
+
+namespace pgk {
+
+template <class T> struct KVLoad;
+template <> struct KVLoad<bf16> {
+    __device__ static __forceinline__ void load8(const bf16* p, float (&f)[8]) {
+        Vec<bf16> v; v.load(p); v.to_float(f);
+    }
+};
+template <> struct KVLoad<f16> {
+    __device__ static __forceinline__ void load8(const f16* p, float (&f)[8]) {
+        Vec<f16> v; v.load(p); v.to_float(f);
+    }
+};
+template <> struct KVLoad<float> {
+    __device__ static __forceinline__ void load8(const float* p, float (&f)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+};
+
+// Partial record per (query head, chunk): [m, l, o[0..D-1]] fp32, o un-normalised (sum p*v).
+template <int D> constexpr int partial_stride() { return D + 2; }
+
+// Running state of one lane-group for G heads.
+template <int G>
+struct DecodeState {
+    float m[G], l[G], o[G][8];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            m[g] = -INFINITY; l[g] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[g][j] = 0.f;
+        }
+    }
+    // fold one position: s[g] = scaled score (already reduced over the row), v = this lane's 8 values
+    __device__ __forceinline__ void update(const float (&s)[G], const float (&v)[8]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float mn = fmaxf(m[g], s[g]);
+            const float alpha = __expf(m[g] - mn);  // m = -inf first time: exp(-inf) = 0
+            const float p = __expf(s[g] - mn);
+            l[g] = l[g] * alpha + p;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[g][j] = fmaf(p, v[j], o[g][j] * alpha);
+            m[g] = mn;
+        }
+    }
+};
+
+// Walk positions [c0, c1) of one KV head's cache rows (row stride D elements).
+// qf[g][8]: this lane's slice of the G pre-scaled queries.  Wave `wid` of 4 takes every 4th
+// position-group.  LPR = D/8 lanes per row.
+template <class T, int D, int G>
+__device__ __forceinline__ void decode_walk(const T* kbase, const T* vbase, int c0, int c1, const float (&qf)[G][8],
+                                            int lane, int wid, DecodeState<G>& st) {
+    constexpr int LPR = D / 8, PPW = 64 / LPR;
+    const int grp = lane / LPR, sub = lane % LPR;
+    for (int p0 = c0 + wid * PPW; p0 < c1; p0 += 4 * PPW) {
+        const int pos = p0 + grp;
+        const bool valid = pos < c1;
+        const int pc = valid ? pos : c1 - 1;  // clamp: loads stay in bounds, result discarded
+        float kf[8], vf[8];
+        KVLoad<T>::load8(kbase + (size_t)pc * D + sub * 8, kf);
+        KVLoad<T>::load8(vbase + (size_t)pc * D + sub * 8, vf);
+        float s[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d = fmaf(qf[g][j], kf[j], d);
+#pragma unroll
+            for (int off = LPR / 2; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
+            s[g] = valid ? d : -INFINITY;
+        }
+        if (valid) st.update(s, vf);  // lane-group uniform
+    }
+}
+
+// Merge the 4 waves x PPW lane-groups of a workgroup and write the chunk's partial records.
+// lds: >= 4*PPW*G*(D+2) floats.  part points at record (head g=0) for this chunk; consecutive
+// heads are `head_stride` floats apart.
+template <int D, int G>
+__device__ __forceinline__ void decode_block_merge(const DecodeState<G>& st, float* lds, float* part,
+                                                   size_t head_stride, int lane, int wid) {
+    constexpr int LPR = D / 8, PPW = 64 / LPR, NS = 4 * PPW, RS = D + 2;
+    const int grp = lane / LPR, sub = lane % LPR;
+    const int slot = wid * PPW + grp;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float* rec = lds + ((size_t)slot * G + g) * RS;
+        if (sub == 0) { rec[0] = st.m[g]; rec[1] = st.l[g]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rec[2 + sub * 8 + j] = st.o[g][j];
+    }
+    __syncthreads();
+    // thread t handles output element (g, d) pairs strided over the block
+    for (int e = threadIdx.x; e < G * D; e += blockDim.x) {
+        const int g = e / D, d = e % D;
+        float mx = -INFINITY;
+        for (int s = 0; s < NS; ++s) mx = fmaxf(mx, lds[((size_t)s * G + g) * RS]);
+        float l = 0.f, o = 0.f;
+        for (int s = 0; s < NS; ++s) {
+            const float* rec = lds + ((size_t)s * G + g) * RS;
+            const float w = (rec[0] == -INFINITY) ? 0.f : __expf(rec[0] - mx);
+            l = fmaf(rec[1], w, l);
+            o = fmaf(rec[2 + d], w, o);
+        }
+        float* outrec = part + (size_t)g * head_stride;
+        outrec[2 + d] = o;
+        if (d == 0) { outrec[0] = mx; outrec[1] = l; }
+    }
+}
+
+// Combine `nsplit` chunk records of one head into the normalised output element d.
+template <int D>
+__device__ __forceinline__ float decode_combine(const float* recs, int nsplit, int d) {
+    constexpr int RS = D + 2;
+    float mx = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, recs[(size_t)s * RS]);
+    float l = 0.f, o = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* rec = recs + (size_t)s * RS;
+        const float w = (rec[0] == -INFINITY) ? 0.f : __expf(rec[0] - mx);
+        l = fmaf(rec[1], w, l);
+        o = fmaf(rec[2 + d], w, o);
+    }
+    return l > 0.f ? o / l : 0.f;
+}
+
+// Chunking rule shared by producer and consumer: nsplit fixed at capture time from max_seq,
+// chunk length derived from the live context length (read from device memory under a graph).
+__device__ __host__ __forceinline__ int decode_chunk_len(int ctx, int nsplit) {
+    int c = (ctx + nsplit - 1) / nsplit;
+    c = (c + 31) & ~31;  // multiples of 32 positions keep every wave-instruction inside one chunk
+    return c < 32 ? 32 : c;
+}
+
+}  // namespace pgk

@@ -1,0 +1,896 @@
+// Native decode / prefill engine for Qwen3 / Llama-shaped causal transformers on gfx950.
+//
+// Decode step = 5 fused weight-streaming kernels per layer + 3 per step, all enqueued by ONE C call
+// and captured into ONE hipGraph whose per-sequence token id and position live in device memory:
+//
+//   embed                    h[b]            = E[token[b]]                         (fp32 residual stream)
+//   per layer
+//     norm_qkv               qkv[b]          = Wqkv . rmsnorm(h[b])
+//     attn                   partials        = split-KV attention; fuses QK-norm, RoPE, KV-cache write
+//     oproj_residual         h[b]           += Wo . combine(partials)
+//     norm_gateup_swiglu     act[b]          = silu(Wg . x) * (Wu . x),  x = rmsnorm(h[b])
+//     down_residual          h[b]           += Wd . act[b]
+//   norm_lmhead              logits[b]       = E . rmsnorm(h[b])  (+ per-workgroup argmax partials)
+//   argmax_finalize          token[b] = argmax (lowest index on ties), position[b] += 1, log token
+//
+// versus ~21 launches + 21 device syncs per layer in the reference's eager step and 2L+2 graphs in its
+// "graph" step (src/pygpukit/llm/decode/m1.py:40-121, m1_graph.py:463-589).
+// The residual stream, q/k/v and the MLP activation stay fp32 between kernels; only the KV cache
+// (bf16) and the weights are rounded.  KV cache layout: [layer][seq][Hkv][max_seq][D] - un-expanded GQA.
+//
+// Prefill runs the MFMA GEMM / flash-attention kernels on bf16 activations with an fp32 residual stream.
+
+#include <type_traits>
+#include <vector>
+
+#include "attn_core.cuh"
+#include "gemv_core.cuh"
+#include "pgk_internal.h"
+
+namespace pgk {
+
+pgk_status engine_gemm_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, void* C, bool accum_f32, int M,
+                          int N, int K, hipStream_t st);
+
+// --------------------------------------------------------------------------------------------
+// Fused GEMV kernel: prologue builds x[M][K] in LDS, body streams W, epilogue consumes y.
+// --------------------------------------------------------------------------------------------
+enum { PRO_NORM = 0, PRO_PLAIN = 1, PRO_ATTN = 2 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3 };
+
+struct FusedArgs {
+    const void* w;        // [N,K] (SWIGLU: [2*N,K], gate rows then up rows)
+    const bf16* wscale;   // fp8 block scales or null
+    int N, K;
+    const float* h;       // PRO_NORM: [M][K] residual stream
+    const bf16* gamma;
+    float eps;
+    const float* xin;     // PRO_PLAIN: [M][K]
+    const float* part;    // PRO_ATTN: [M][Hq][nsplit][D+2]
+    int nsplit, hq, d;
+    float* out;           // [M][ld_out]
+    int ld_out;
+    float* amax_val;      // EPI_LOGITS: [M][gridDim.x]
+    int* amax_idx;
+};
+
+template <class XT> __device__ __forceinline__ void store_x(XT* xs, int i, float v);
+template <> __device__ __forceinline__ void store_x<float>(float* xs, int i, float v) { xs[i] = v; }
+template <> __device__ __forceinline__ void store_x<bf16>(bf16* xs, int i, float v) { xs[i] = from_f<bf16>(v); }
+
+template <class WT, class XT, int M, int R, int PRO, int EPI>
+__global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    XT* xs = reinterpret_cast<XT*>(smem);  // [M][K]
+    __shared__ float red[16];
+    __shared__ float s_bv[4][M];
+    __shared__ int s_bi[4][M];
+    const int K = a.K, N = a.N;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+
+    // ---- prologue ----
+    if constexpr (PRO == PRO_NORM) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const float* hr = a.h + (size_t)m * K;
+            float ss = 0.f;
+            for (int i = threadIdx.x; i < K; i += 256) { const float v = hr[i]; ss = fmaf(v, v, ss); }
+            ss = block_sum(ss, red);
+            const float inv = 1.0f / sqrtf(ss / K + a.eps);
+            for (int i = threadIdx.x; i < K; i += 256) store_x<XT>(xs, m * K + i, hr[i] * inv * to_f(a.gamma[i]));
+        }
+    } else if constexpr (PRO == PRO_PLAIN) {
+        for (int i = threadIdx.x; i < M * K; i += 256) store_x<XT>(xs, i, a.xin[i]);
+    } else {  // PRO_ATTN: K == hq * d
+        const int RS = a.d + 2;
+        for (int i = threadIdx.x; i < M * K; i += 256) {
+            const int m = i / K, e = i % K, hh = e / a.d, dd = e % a.d;
+            const float* recs = a.part + ((size_t)m * a.hq + hh) * a.nsplit * RS;
+            float mx = -INFINITY;
+            for (int s = 0; s < a.nsplit; ++s) mx = fmaxf(mx, recs[(size_t)s * RS]);
+            float l = 0.f, o = 0.f;
+            for (int s = 0; s < a.nsplit; ++s) {
+                const float* rec = recs + (size_t)s * RS;
+                const float w = (rec[0] == -INFINITY) ? 0.f : __expf(rec[0] - mx);
+                l = fmaf(rec[1], w, l);
+                o = fmaf(rec[2 + dd], w, o);
+            }
+            store_x<XT>(xs, i, l > 0.f ? o / l : 0.f);
+        }
+    }
+    __syncthreads();
+
+    // ---- body ----
+    constexpr int OUT_PER_TRIP = (EPI == EPI_SWIGLU) ? R / 2 : R;
+    const int wave = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
+    float best_v[M];
+    int best_i[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) { best_v[m] = -INFINITY; best_i[m] = 0x7FFFFFFF; }
+
+    for (int g = wave; g * OUT_PER_TRIP < N; g += nwaves) {
+        const int n0 = g * OUT_PER_TRIP;
+        const WT* wrow[R];
+        const bf16* srow[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int row;
+            if constexpr (EPI == EPI_SWIGLU) row = (r < R / 2) ? min(n0 + r, N - 1) : N + min(n0 + r - R / 2, N - 1);
+            else row = min(n0 + r, N - 1);
+            wrow[r] = reinterpret_cast<const WT*>(a.w) + (size_t)row * K;
+            srow[r] = a.wscale ? a.wscale + (size_t)(row >> 7) * (K >> 7) : nullptr;
+        }
+        float acc[R][M];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
+        if constexpr (std::is_same<WT, fp8e4m3>::value) gemv_rows_fp8<XT, M, R>(wrow, srow, xs, K, K, lane, acc);
+        else gemv_rows<WT, XT, M, R>(wrow, xs, K, K, lane, acc);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int m = 0; m < M; ++m) acc[r][m] = wave_sum(acc[r][m]);
+        // ---- epilogue (lane 0 of the wave) ----
+        if (lane == 0) {
+            if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+                for (int r = 0; r < R / 2; ++r)
+                    if (n0 + r < N) {
+#pragma unroll
+                        for (int m = 0; m < M; ++m) {
+                            const float gt = acc[r][m], up = acc[r + R / 2][m];
+                            a.out[(size_t)m * a.ld_out + n0 + r] = gt / (1.0f + __expf(-gt)) * up;
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (n0 + r < N) {
+#pragma unroll
+                        for (int m = 0; m < M; ++m) {
+                            float* o = a.out + (size_t)m * a.ld_out + n0 + r;
+                            if constexpr (EPI == EPI_RESID) *o += acc[r][m];
+                            else *o = acc[r][m];
+                            if constexpr (EPI == EPI_LOGITS) {
+                                if (acc[r][m] > best_v[m]) { best_v[m] = acc[r][m]; best_i[m] = n0 + r; }
+                            }
+                        }
+                    }
+            }
+        }
+    }
+    if constexpr (EPI == EPI_LOGITS) {
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) { s_bv[wid][m] = best_v[m]; s_bi[wid][m] = best_i[m]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < M) {
+            const int m = threadIdx.x;
+            float bv = s_bv[0][m];
+            int bi = s_bi[0][m];
+            for (int w = 1; w < 4; ++w)
+                if (s_bv[w][m] > bv || (s_bv[w][m] == bv && s_bi[w][m] < bi)) { bv = s_bv[w][m]; bi = s_bi[w][m]; }
+            a.amax_val[(size_t)m * gridDim.x + blockIdx.x] = bv;
+            a.amax_idx[(size_t)m * gridDim.x + blockIdx.x] = bi;
+        }
+    }
+}
+
+// h[b][:] = E[token[b]][:]
+__global__ void embed_kernel(const bf16* embed, const int32_t* tokens, float* h, int H) {
+    const int b = blockIdx.x;
+    const bf16* row = embed + (size_t)tokens[b] * H;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) h[(size_t)b * H + i] = to_f(row[i]);
+}
+
+// token[b] = argmax over workgroup partials (ties -> lowest index); position[b] += 1; log.
+__global__ void argmax_finalize_kernel(const float* amax_val, const int* amax_idx, int nblk, int32_t* tokens,
+                                       int32_t* positions, int32_t* token_log, int32_t* step_counter, int batch,
+                                       int log_cap) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int b = blockIdx.x;
+    float bv = -INFINITY;
+    int bi = 0x7FFFFFFF;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+        const float v = amax_val[(size_t)b * nblk + i];
+        const int ix = amax_idx[(size_t)b * nblk + i];
+        if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { sv[wid] = bv; si[wid] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        for (int w = 1; w < nw; ++w)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        if (bi == 0x7FFFFFFF) bi = 0;
+        tokens[b] = bi;
+        positions[b] += 1;
+        const int step = step_counter[0];
+        if (step < log_cap) token_log[(size_t)step * batch + b] = bi;
+    }
+}
+__global__ void bump_step_kernel(int32_t* step_counter) { step_counter[0] += 1; }
+
+// --------------------------------------------------------------------------------------------
+// Decode attention with fused QK-norm + RoPE + KV-cache write.
+// grid (nsplit, Hkv, batch); qkv[b] = [q (Hq*D) | k (Hkv*D) | v (Hkv*D)] fp32, pre-norm.
+// --------------------------------------------------------------------------------------------
+template <int D, int G>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const float* qkv, int qkv_ld, const bf16* q_gamma,
+                                                          const bf16* k_gamma, float eps, const float* rope_cos,
+                                                          const float* rope_sin, bf16* kcache, bf16* vcache,
+                                                          const int32_t* positions, float* part, int hq, int hkv,
+                                                          int max_seq, int nsplit, float scale) {
+    constexpr int LPR = D / 8, PPW = 64 / LPR, RS = D + 2, HALF = D / 2;
+    __shared__ float lds[4 * PPW * G * RS];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int sub = lane % LPR;
+    const int kvh = blockIdx.y, b = blockIdx.z;
+    const int pos = positions[b];                    // position of the token being decoded
+    const int ctx = min(pos + 1, max_seq);
+    const float* row = qkv + (size_t)b * qkv_ld;
+    const float* cs = rope_cos + (size_t)min(pos, max_seq - 1) * HALF;
+    const float* sn = rope_sin + (size_t)min(pos, max_seq - 1) * HALF;
+
+    // norm + rope of one head vector; this lane holds dims sub*8 .. +8, the rotate-half partner
+    // dims live LPR/2 lanes away.
+    auto norm_rope = [&](const float* src, const bf16* gamma, float (&o)[8]) {
+        float x[8];
+        const float4 a = *reinterpret_cast<const float4*>(src + sub * 8), c = *reinterpret_cast<const float4*>(src + sub * 8 + 4);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = c.w;
+        if (gamma) {
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss = fmaf(x[j], x[j], ss);
+#pragma unroll
+            for (int off = LPR / 2; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+            const float inv = 1.0f / sqrtf(ss / D + eps);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = x[j] * inv * to_f(gamma[sub * 8 + j]);
+        }
+        const bool lo = sub < LPR / 2;  // first half of the head dims
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float other = __shfl_xor(x[j], LPR / 2, 64);
+            const int dd = (sub * 8 + j) % HALF;
+            const float c_ = cs[dd], s_ = sn[dd];
+            // x0' = x0*c - x1*s ; x1' = x1*c + x0*s
+            o[j] = lo ? (x[j] * c_ - other * s_) : (x[j] * c_ + other * s_);
+        }
+    };
+
+    float qf[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        norm_rope(row + (size_t)(kvh * G + g) * D, q_gamma, qf[g]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[g][j] *= scale;
+    }
+    float kn[8], vn[8];
+    norm_rope(row + (size_t)hq * D + (size_t)kvh * D, k_gamma, kn);
+    {
+        const float* vsrc = row + (size_t)(hq + hkv) * D + (size_t)kvh * D + sub * 8;
+        const float4 a = *reinterpret_cast<const float4*>(vsrc), c = *reinterpret_cast<const float4*>(vsrc + 4);
+        vn[0] = a.x; vn[1] = a.y; vn[2] = a.z; vn[3] = a.w; vn[4] = c.x; vn[5] = c.y; vn[6] = c.z; vn[7] = c.w;
+    }
+    // the cache holds bf16: use the rounded values for this step too (same as reading them back)
+    Vec<bf16> kb, vb;
+    kb.from_float(kn);
+    vb.from_float(vn);
+    kb.to_float(kn);
+    vb.to_float(vn);
+
+    const size_t head_off = (((size_t)b * hkv + kvh) * max_seq) * D;
+    const int chunk = decode_chunk_len(ctx, nsplit);
+    const int c0 = min(blockIdx.x * chunk, ctx), c1 = min(c0 + chunk, ctx);
+    const bool owns_new = (pos < max_seq) && (pos >= c0) && (pos < c1);
+    if (owns_new && wid == 0 && lane < LPR) {
+        kb.store(kcache + head_off + (size_t)pos * D + sub * 8);
+        vb.store(vcache + head_off + (size_t)pos * D + sub * 8);
+    }
+    DecodeState<G> st;
+    st.init();
+    // cached positions of this chunk, excluding the token being written right now
+    decode_walk<bf16, D, G>(kcache + head_off, vcache + head_off, c0, owns_new ? min(c1, pos) : c1, qf, lane, wid, st);
+    if (owns_new && wid == 0 && lane < LPR) {  // lane-group 0 of wave 0 folds the new token from registers
+        float s[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float dsum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dsum = fmaf(qf[g][j], kn[j], dsum);
+#pragma unroll
+            for (int off = LPR / 2; off >= 1; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
+            s[g] = dsum;
+        }
+        st.update(s, vn);
+    }
+    decode_block_merge<D, G>(st, lds, part + (((size_t)b * hq + (size_t)kvh * G) * nsplit + blockIdx.x) * RS,
+                             (size_t)nsplit * RS, lane, wid);
+}
+
+// --------------------------------------------------------------------------------------------
+// Prefill helpers (bf16 activations, fp32 residual stream)
+// --------------------------------------------------------------------------------------------
+__global__ void embed_rows_kernel(const bf16* embed, const int32_t* tokens, float* h, int H) {
+    const int s = blockIdx.x;
+    const bf16* row = embed + (size_t)tokens[s] * H;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) h[(size_t)s * H + i] = to_f(row[i]);
+}
+
+// x_bf16[s] = rmsnorm(h32[s]) * gamma ; one wave per row
+__global__ __launch_bounds__(256) void rmsnorm_f32_bf16_kernel(const float* h, const bf16* gamma, bf16* out, int rows,
+                                                               int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* hr = h + (size_t)row * H;
+    float ss = 0.f;
+    for (int i = lane * 4; i < H; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(hr + i);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(ss / H + eps);
+    for (int i = lane * 4; i < H; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(hr + i);
+        const uint2 g = *reinterpret_cast<const uint2*>(gamma + i);
+        const float g0 = __uint_as_float(g.x << 16), g1 = __uint_as_float(g.x & 0xFFFF0000u);
+        const float g2 = __uint_as_float(g.y << 16), g3 = __uint_as_float(g.y & 0xFFFF0000u);
+        uint2 o;
+        o.x = pack_bf16x2(v.x * inv * g0, v.y * inv * g1);
+        o.y = pack_bf16x2(v.z * inv * g2, v.w * inv * g3);
+        *reinterpret_cast<uint2*>(out + (size_t)row * H + i) = o;
+    }
+}
+
+// Per (token s, head slot hh) of qkv[n][(Hq+2Hkv)*D] bf16: q heads -> norm+rope in place;
+// k heads -> norm+rope -> cache row; v heads -> cache row.  One lane-group of D/8 lanes per vector.
+template <int D>
+__global__ __launch_bounds__(256) void qknorm_rope_kvwrite_kernel(bf16* qkv, const bf16* q_gamma, const bf16* k_gamma,
+                                                                  float eps, const float* rope_cos,
+                                                                  const float* rope_sin, bf16* kcache, bf16* vcache,
+                                                                  int n, int hq, int hkv, int max_seq, int start_pos) {
+    constexpr int LPR = D / 8, HALF = D / 2, VPB = 256 / LPR;
+    const int nslots = hq + 2 * hkv;
+    const long long vec = (long long)blockIdx.x * VPB + threadIdx.x / LPR;
+    const int sub = threadIdx.x % LPR;
+    const bool live = vec < (long long)n * nslots;
+    const long long vv = live ? vec : 0;
+    const int s = (int)(vv / nslots), hh = (int)(vv % nslots);
+    bf16* src = qkv + (size_t)s * nslots * D + (size_t)hh * D + sub * 8;
+    float x[8];
+    Vec<bf16> raw;
+    raw.load(src);
+    raw.to_float(x);
+    const int pos = start_pos + s;
+    const bool is_q = hh < hq, is_k = !is_q && hh < hq + hkv;
+    if (is_q || is_k) {
+        const bf16* gamma = is_q ? q_gamma : k_gamma;
+        if (gamma) {
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss = fmaf(x[j], x[j], ss);
+#pragma unroll
+            for (int off = LPR / 2; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+            const float inv = 1.0f / sqrtf(ss / D + eps);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = x[j] * inv * to_f(gamma[sub * 8 + j]);
+        }
+        const bool lo = sub < LPR / 2;
+        const float* cs = rope_cos + (size_t)min(pos, max_seq - 1) * HALF;
+        const float* sn = rope_sin + (size_t)min(pos, max_seq - 1) * HALF;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float other = __shfl_xor(x[j], LPR / 2, 64);
+            const int dd = (sub * 8 + j) % HALF;
+            o[j] = lo ? (x[j] * cs[dd] - other * sn[dd]) : (x[j] * cs[dd] + other * sn[dd]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = o[j];
+    }
+    if (!live) return;
+    Vec<bf16> ov;
+    ov.from_float(x);
+    if (is_q) {
+        ov.store(src);
+    } else if (pos < max_seq) {
+        const int kvh = is_k ? hh - hq : hh - hq - hkv;
+        bf16* dst = (is_k ? kcache : vcache) + ((size_t)kvh * max_seq + pos) * D + sub * 8;
+        ov.store(dst);
+    }
+}
+
+// act[s][i] = silu(gu[s][i]) * gu[s][I+i]   (bf16 in/out, fp32 math)
+__global__ void swiglu_rows_kernel(const bf16* gu, bf16* act, int n, int I) {
+    const size_t total = (size_t)n * I / 8;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += stride) {
+        const size_t s = t / (I / 8), c = t % (I / 8);
+        Vec<bf16> g, u;
+        g.load(gu + s * 2 * I + c * 8);
+        u.load(gu + s * 2 * I + I + c * 8);
+        float gf[8], uf[8];
+        g.to_float(gf);
+        u.to_float(uf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gf[j] = gf[j] / (1.0f + __expf(-gf[j])) * uf[j];
+        g.from_float(gf);
+        g.store(act + s * I + c * 8);
+    }
+}
+
+__global__ void bf16_rows_to_f32_kernel(const bf16* in, float* out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) out[i] = to_f(in[i]);
+}
+
+// --------------------------------------------------------------------------------------------
+struct Engine {
+    pgk_model_config_t cfg;
+    const bf16 *embed, *lm_head, *final_norm;
+    std::vector<pgk_layer_weights_t> layers;
+    int nsplit = 1, lm_blocks = 1, log_cap = 4096;
+    // device state
+    bf16 *kcache = nullptr, *vcache = nullptr;
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    int32_t *tokens = nullptr, *positions = nullptr, *token_log = nullptr, *step_counter = nullptr;
+    float *h = nullptr, *qkv = nullptr, *part = nullptr, *act = nullptr, *logits = nullptr, *amax_val = nullptr;
+    int* amax_idx = nullptr;
+    size_t kv_bytes = 0, ws_bytes = 0;
+    // prefill workspace (grown on demand, outside capture)
+    void* pf = nullptr;
+    size_t pf_bytes = 0;
+    int32_t* pf_tokens = nullptr;
+    int pf_tokens_cap = 0;
+    // captured step
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int graph_batch = 0;
+    int launches_per_step = 0;
+    std::vector<void*> allocs;
+
+    size_t kv_layer_elems() const { return (size_t)cfg.max_batch * cfg.num_kv_heads * cfg.max_seq_len * cfg.head_dim; }
+    int qkv_dim() const { return (cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim; }
+};
+
+static pgk_status dev_alloc(Engine* e, void** p, size_t bytes, size_t* acct) {
+    pgk_status r = pgk_malloc(p, bytes);
+    if (r != PGK_OK) return r;
+    e->allocs.push_back(*p);
+    if (acct) *acct += bytes;
+    return PGK_OK;
+}
+
+template <class WT, class XT, int M, int R, int PRO, int EPI>
+static pgk_status launch_fused(const FusedArgs& a, int n_out, hipStream_t st, int force_grid = 0) {
+    constexpr int OUT_PER_TRIP = (EPI == EPI_SWIGLU) ? R / 2 : R;
+    const size_t lds = (size_t)M * a.K * sizeof(XT);
+    PGK_REQUIRE(lds <= 156 * 1024, "engine: %d activation rows of K=%d do not fit LDS", M, a.K);
+    auto kfn = &fused_gemv_kernel<WT, XT, M, R, PRO, EPI>;
+    static bool attr_done = false;
+    if (lds > 48 * 1024 && !attr_done) {
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        attr_done = true;
+    }
+    int grid = force_grid ? force_grid : ceil_div(n_out, OUT_PER_TRIP * 4);
+    if (grid > 1024) grid = 1024;
+    kfn<<<grid, 256, lds, st>>>(a);
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
+}
+
+// rows-per-wave heuristic: enough workgroups to cover 256 CUs even for the N = hidden projections
+template <class WT, class XT, int M, int PRO, int EPI>
+static pgk_status launch_fused_auto(const FusedArgs& a, int n_out, hipStream_t st, int force_grid = 0) {
+    if constexpr (EPI == EPI_SWIGLU) {
+        if (n_out >= 4096) return launch_fused<WT, XT, M, 4, PRO, EPI>(a, n_out, st, force_grid);
+        return launch_fused<WT, XT, M, 2, PRO, EPI>(a, n_out, st, force_grid);
+    } else {
+        if (n_out >= 4096) return launch_fused<WT, XT, M, 4, PRO, EPI>(a, n_out, st, force_grid);
+        if (n_out >= 2048) return launch_fused<WT, XT, M, 2, PRO, EPI>(a, n_out, st, force_grid);
+        return launch_fused<WT, XT, M, 1, PRO, EPI>(a, n_out, st, force_grid);
+    }
+}
+
+template <int D>
+static pgk_status launch_attn(Engine* e, int layer, int b0, int m, hipStream_t st) {
+    const auto& c = e->cfg;
+    const auto& L = e->layers[layer];
+    const int G = c.num_heads / c.num_kv_heads;
+    const size_t lofs = (size_t)layer * e->kv_layer_elems() + (size_t)b0 * c.num_kv_heads * c.max_seq_len * c.head_dim;
+    dim3 grid(e->nsplit, c.num_kv_heads, m);
+    const float scale = 1.0f / sqrtf((float)D);
+    const float* qkv = e->qkv + (size_t)b0 * e->qkv_dim();
+    float* part = e->part + (size_t)b0 * c.num_heads * e->nsplit * (D + 2);
+    const bf16* qg = c.use_qk_norm ? (const bf16*)L.q_norm : nullptr;
+    const bf16* kg = c.use_qk_norm ? (const bf16*)L.k_norm : nullptr;
+#define PGK_ATTN(GG)                                                                                                   \
+    case GG:                                                                                                           \
+        attn_decode_kernel<D, GG><<<grid, 256, 0, st>>>(qkv, e->qkv_dim(), qg, kg, c.norm_eps, e->rope_cos, e->rope_sin, \
+                                                        e->kcache + lofs, e->vcache + lofs, e->positions + b0, part,  \
+                                                        c.num_heads, c.num_kv_heads, c.max_seq_len, e->nsplit, scale); \
+        break;
+    switch (G) {
+        PGK_ATTN(1) PGK_ATTN(2) PGK_ATTN(4)
+        default: return set_error(PGK_ERR_UNSUPPORTED, "engine: GQA group %d not in {1,2,4}", G);
+    }
+#undef PGK_ATTN
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
+}
+
+// One decode step for sequences [b0, b0+M)
+template <class WT, class XT, int M>
+static pgk_status decode_chunk(Engine* e, int b0, hipStream_t st, int* launches) {
+    const auto& c = e->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size, D = c.head_dim, QD = c.num_heads * D, NQKV = e->qkv_dim();
+    float* h = e->h + (size_t)b0 * H;
+    embed_kernel<<<M, 256, 0, st>>>(e->embed, e->tokens + b0, h, H);
+    PGK_CHECK_HIP(hipGetLastError());
+    ++*launches;
+    for (int l = 0; l < c.num_layers; ++l) {
+        const auto& L = e->layers[l];
+        FusedArgs a{};
+        // 1. qkv = Wqkv . rmsnorm(h)
+        a.w = L.w_qkv; a.wscale = (const bf16*)L.s_qkv; a.N = NQKV; a.K = H;
+        a.h = h; a.gamma = (const bf16*)L.attn_norm; a.eps = c.norm_eps;
+        a.out = e->qkv + (size_t)b0 * NQKV; a.ld_out = NQKV;
+        if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM, EPI_STORE>(a, NQKV, st)) return r;
+        // 2. attention (QK-norm, RoPE, KV write fused)
+        if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, st)) return r; }
+        else { if (pgk_status r = launch_attn<64>(e, l, b0, M, st)) return r; }
+        // 3. h += Wo . attn
+        a = FusedArgs{};
+        a.w = L.w_o; a.wscale = (const bf16*)L.s_o; a.N = H; a.K = QD;
+        a.part = e->part + (size_t)b0 * c.num_heads * e->nsplit * (D + 2); a.nsplit = e->nsplit; a.hq = c.num_heads; a.d = D;
+        a.out = h; a.ld_out = H;
+        if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_ATTN, EPI_RESID>(a, H, st)) return r;
+        // 4. act = silu(Wg x) * (Wu x), x = rmsnorm(h)
+        a = FusedArgs{};
+        a.w = L.w_gate_up; a.wscale = (const bf16*)L.s_gate_up; a.N = I; a.K = H;
+        a.h = h; a.gamma = (const bf16*)L.mlp_norm; a.eps = c.norm_eps;
+        a.out = e->act + (size_t)b0 * I; a.ld_out = I;
+        if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM, EPI_SWIGLU>(a, I, st)) return r;
+        // 5. h += Wd . act
+        a = FusedArgs{};
+        a.w = L.w_down; a.wscale = (const bf16*)L.s_down; a.N = H; a.K = I;
+        a.xin = e->act + (size_t)b0 * I;
+        a.out = h; a.ld_out = H;
+        if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_PLAIN, EPI_RESID>(a, H, st)) return r;
+        *launches += 5;
+    }
+    // logits = E . rmsnorm(h)  (lm_head stays bf16 even when the linears are fp8)
+    FusedArgs a{};
+    a.w = e->lm_head; a.N = c.vocab_size; a.K = H;
+    a.h = h; a.gamma = e->final_norm; a.eps = c.norm_eps;
+    a.out = e->logits + (size_t)b0 * c.vocab_size; a.ld_out = c.vocab_size;
+    a.amax_val = e->amax_val + (size_t)b0 * e->lm_blocks; a.amax_idx = e->amax_idx + (size_t)b0 * e->lm_blocks;
+    if (pgk_status r = launch_fused<bf16, XT, M, 4, PRO_NORM, EPI_LOGITS>(a, c.vocab_size, st, e->lm_blocks)) return r;
+    argmax_finalize_kernel<<<M, 256, 0, st>>>(e->amax_val + (size_t)b0 * e->lm_blocks, e->amax_idx + (size_t)b0 * e->lm_blocks,
+                                              e->lm_blocks, e->tokens + b0, e->positions + b0, e->token_log + b0,
+                                              e->step_counter, e->cfg.max_batch, e->log_cap);
+    PGK_CHECK_HIP(hipGetLastError());
+    *launches += 2;
+    return PGK_OK;
+}
+
+template <class WT>
+static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* launches) {
+    int b0 = 0;
+    while (b0 < batch) {
+        const int rem = batch - b0;
+        pgk_status r;
+        if (rem >= 8) { r = decode_chunk<WT, bf16, 8>(e, b0, st, launches); b0 += 8; }
+        else if (rem >= 4) { r = decode_chunk<WT, bf16, 4>(e, b0, st, launches); b0 += 4; }
+        else if (rem >= 2) { r = decode_chunk<WT, float, 2>(e, b0, st, launches); b0 += 2; }
+        else { r = decode_chunk<WT, float, 1>(e, b0, st, launches); b0 += 1; }
+        if (r != PGK_OK) return r;
+    }
+    bump_step_kernel<<<1, 1, 0, st>>>(e->step_counter);
+    PGK_CHECK_HIP(hipGetLastError());
+    ++*launches;
+    return PGK_OK;
+}
+
+static pgk_status decode_step(Engine* e, int batch, hipStream_t st, int* launches) {
+    if (e->cfg.weight_format == 1) return decode_step_impl<fp8e4m3>(e, batch, st, launches);
+    return decode_step_impl<bf16>(e, batch, st, launches);
+}
+
+}  // namespace pgk
+
+using namespace pgk;
+
+extern "C" {
+
+pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, const void* lm_head,
+                             const void* final_norm, const pgk_layer_weights_t* layers, pgk_engine* out) {
+    PGK_REQUIRE(cfg && embed && final_norm && layers && out, "pgk_engine_create: null argument");
+    const auto& c = *cfg;
+    PGK_REQUIRE(c.head_dim == 128 || c.head_dim == 64, "pgk_engine_create: head_dim %d not in {64,128}", c.head_dim);
+    PGK_REQUIRE(c.num_heads % c.num_kv_heads == 0, "pgk_engine_create: Hq %d %% Hkv %d", c.num_heads, c.num_kv_heads);
+    const int G = c.num_heads / c.num_kv_heads;
+    PGK_REQUIRE(G == 1 || G == 2 || G == 4, "pgk_engine_create: GQA group %d not in {1,2,4}", G);
+    PGK_REQUIRE(c.hidden_size % 16 == 0 && c.intermediate_size % 16 == 0, "pgk_engine_create: sizes must be multiples of 16");
+    PGK_REQUIRE(c.weight_format == 0 || (c.hidden_size % 128 == 0 && c.intermediate_size % 128 == 0),
+                "pgk_engine_create: fp8 weights need 128-multiple dims");
+    PGK_REQUIRE(c.max_batch >= 1 && c.max_seq_len >= 1 && c.num_layers >= 1, "pgk_engine_create: bad sizes");
+    Engine* e = new Engine();
+    e->cfg = c;
+    e->embed = (const bf16*)embed;
+    e->lm_head = (const bf16*)(lm_head ? lm_head : embed);
+    e->final_norm = (const bf16*)final_norm;
+    e->layers.assign(layers, layers + c.num_layers);
+    int nsplit = (c.max_seq_len + 255) / 256;
+    e->nsplit = nsplit < 1 ? 1 : (nsplit > 32 ? 32 : nsplit);
+    e->lm_blocks = 1024;
+    const int B = c.max_batch, H = c.hidden_size, D = c.head_dim;
+    pgk_status r = PGK_OK;
+    auto A = [&](void** p, size_t bytes, size_t* acct) { if (r == PGK_OK) r = dev_alloc(e, p, bytes, acct); };
+    const size_t kvb = (size_t)c.num_layers * e->kv_layer_elems() * sizeof(bf16);
+    A((void**)&e->kcache, kvb, &e->kv_bytes);
+    A((void**)&e->vcache, kvb, &e->kv_bytes);
+    A((void**)&e->rope_cos, (size_t)c.max_seq_len * (D / 2) * 4, &e->ws_bytes);
+    A((void**)&e->rope_sin, (size_t)c.max_seq_len * (D / 2) * 4, &e->ws_bytes);
+    A((void**)&e->tokens, (size_t)B * 4, &e->ws_bytes);
+    A((void**)&e->positions, (size_t)B * 4, &e->ws_bytes);
+    A((void**)&e->token_log, (size_t)e->log_cap * B * 4, &e->ws_bytes);
+    A((void**)&e->step_counter, 16, &e->ws_bytes);
+    A((void**)&e->h, (size_t)B * H * 4, &e->ws_bytes);
+    A((void**)&e->qkv, (size_t)B * e->qkv_dim() * 4, &e->ws_bytes);
+    A((void**)&e->part, (size_t)B * c.num_heads * e->nsplit * (D + 2) * 4, &e->ws_bytes);
+    A((void**)&e->act, (size_t)B * c.intermediate_size * 4, &e->ws_bytes);
+    A((void**)&e->logits, (size_t)B * c.vocab_size * 4, &e->ws_bytes);
+    A((void**)&e->amax_val, (size_t)B * e->lm_blocks * 4, &e->ws_bytes);
+    A((void**)&e->amax_idx, (size_t)B * e->lm_blocks * 4, &e->ws_bytes);
+    if (r != PGK_OK) { pgk_engine_destroy(e); return r; }
+    // RoPE tables in fp32, same formula as the reference (src/pygpukit/llm/layers/rope.py:13-24):
+    // freqs = 1/theta^(2i/D) in fp32, angle = float(t) * freq in fp32, cos/sin of that.
+    {
+        std::vector<float> hc((size_t)c.max_seq_len * (D / 2)), hs(hc.size());
+        for (int i = 0; i < D / 2; ++i) {
+            const float expo = (float)(2 * i) / (float)D;
+            const float freq = 1.0f / powf(c.rope_theta, expo);
+            for (int t = 0; t < c.max_seq_len; ++t) {
+                const float ang = (float)t * freq;
+                hc[(size_t)t * (D / 2) + i] = (float)cos((double)ang);
+                hs[(size_t)t * (D / 2) + i] = (float)sin((double)ang);
+            }
+        }
+        hipStream_t st = resolve_stream(nullptr);
+        hipError_t he = hipMemcpyAsync(e->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, st);
+        if (he == hipSuccess) he = hipMemcpyAsync(e->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, st);
+        if (he == hipSuccess) he = hipMemsetAsync(e->kcache, 0, kvb, st);
+        if (he == hipSuccess) he = hipMemsetAsync(e->vcache, 0, kvb, st);
+        if (he == hipSuccess) he = hipMemsetAsync(e->tokens, 0, (size_t)B * 4, st);
+        if (he == hipSuccess) he = hipMemsetAsync(e->positions, 0, (size_t)B * 4, st);
+        if (he == hipSuccess) he = hipMemsetAsync(e->step_counter, 0, 16, st);
+        if (he == hipSuccess) he = hipStreamSynchronize(st);
+        if (he != hipSuccess) { pgk_engine_destroy(e); return set_error(PGK_ERR_HIP, "pgk_engine_create: %s", hipGetErrorString(he)); }
+    }
+    *out = e;
+    return PGK_OK;
+}
+
+pgk_status pgk_engine_destroy(pgk_engine eh) {
+    if (!eh) return PGK_OK;
+    Engine* e = (Engine*)eh;
+    if (e->exec) (void)hipGraphExecDestroy(e->exec);
+    if (e->graph) (void)hipGraphDestroy(e->graph);
+    for (void* p : e->allocs) (void)pgk_free(p);
+    if (e->pf) (void)pgk_free(e->pf);
+    if (e->pf_tokens) (void)pgk_free(e->pf_tokens);
+    delete e;
+    return PGK_OK;
+}
+
+pgk_status pgk_engine_bytes(pgk_engine eh, size_t* kv_bytes, size_t* workspace_bytes) {
+    PGK_REQUIRE(eh, "pgk_engine_bytes: null engine");
+    Engine* e = (Engine*)eh;
+    if (kv_bytes) *kv_bytes = e->kv_bytes;
+    if (workspace_bytes) *workspace_bytes = e->ws_bytes + e->pf_bytes;
+    return PGK_OK;
+}
+
+pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, int n, int start_pos, void* all_logits,
+                              float* h_last_logits, pgk_stream s) {
+    PGK_REQUIRE(eh && h_tokens, "pgk_engine_prefill: null argument");
+    Engine* e = (Engine*)eh;
+    const auto& c = e->cfg;
+    PGK_REQUIRE(seq >= 0 && seq < c.max_batch, "pgk_engine_prefill: sequence slot %d outside [0,%d)", seq, c.max_batch);
+    PGK_REQUIRE(n >= 1 && start_pos >= 0 && start_pos + n <= c.max_seq_len, "pgk_engine_prefill: positions %d..%d outside cache of %d",
+                start_pos, start_pos + n, c.max_seq_len);
+    hipStream_t st = resolve_stream(s);
+    const int H = c.hidden_size, I = c.intermediate_size, D = c.head_dim, QD = c.num_heads * D, NQKV = e->qkv_dim();
+    // workspace: h32 [n,H] f32 | x [n,H] | qkv [n,NQKV] | attn [n,QD] | gu [n,2I] | act [n,I]  (bf16)
+    const size_t need = (size_t)n * H * 4 + ((size_t)n * H + (size_t)n * NQKV + (size_t)n * QD + (size_t)n * 2 * I + (size_t)n * I) * 2 + 256;
+    if (need > e->pf_bytes) {
+        if (e->pf) PGK_CHECK_HIP(hipStreamSynchronize(st));
+        if (e->pf) pgk_free(e->pf);
+        e->pf = nullptr;
+        if (pgk_status r = pgk_malloc(&e->pf, need)) return r;
+        e->pf_bytes = need;
+    }
+    if (n > e->pf_tokens_cap) {
+        if (e->pf_tokens) { PGK_CHECK_HIP(hipStreamSynchronize(st)); pgk_free(e->pf_tokens); }
+        if (pgk_status r = pgk_malloc((void**)&e->pf_tokens, (size_t)n * 4)) return r;
+        e->pf_tokens_cap = n;
+    }
+    for (int i = 0; i < n; ++i)
+        PGK_REQUIRE(h_tokens[i] >= 0 && h_tokens[i] < c.vocab_size, "pgk_engine_prefill: token %d out of range", h_tokens[i]);
+    PGK_CHECK_HIP(hipMemcpyAsync(e->pf_tokens, h_tokens, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    PGK_CHECK_HIP(hipStreamSynchronize(st));  // h_tokens may be pageable: make the copy complete before returning control
+    char* p = (char*)e->pf;
+    float* h32 = (float*)p; p += (size_t)n * H * 4;
+    bf16* x = (bf16*)p; p += (size_t)n * H * 2;
+    bf16* qkv = (bf16*)p; p += (size_t)n * NQKV * 2;
+    bf16* attn = (bf16*)p; p += (size_t)n * QD * 2;
+    bf16* gu = (bf16*)p; p += (size_t)n * 2 * I * 2;
+    bf16* act = (bf16*)p;
+    const bool fp8 = c.weight_format == 1;
+    embed_rows_kernel<<<n, 256, 0, st>>>(e->embed, e->pf_tokens, h32, H);
+    PGK_LAUNCH_CHECK();
+    const int kv_len = start_pos + n;
+    for (int l = 0; l < c.num_layers; ++l) {
+        const auto& L = e->layers[l];
+        bf16* kc = e->kcache + (size_t)l * e->kv_layer_elems() + (size_t)seq * c.num_kv_heads * c.max_seq_len * D;
+        bf16* vc = e->vcache + (size_t)l * e->kv_layer_elems() + (size_t)seq * c.num_kv_heads * c.max_seq_len * D;
+        rmsnorm_f32_bf16_kernel<<<ceil_div(n, 4), 256, 0, st>>>(h32, (const bf16*)L.attn_norm, x, n, H, c.norm_eps);
+        PGK_LAUNCH_CHECK();
+        if (pgk_status r = engine_gemm_nt(x, L.w_qkv, (const bf16*)L.s_qkv, fp8, qkv, false, n, NQKV, H, st)) return r;
+        {
+            const int nslots = c.num_heads + 2 * c.num_kv_heads;
+            const bf16* qg = c.use_qk_norm ? (const bf16*)L.q_norm : nullptr;
+            const bf16* kg = c.use_qk_norm ? (const bf16*)L.k_norm : nullptr;
+            if (D == 128)
+                qknorm_rope_kvwrite_kernel<128><<<ceil_div((long long)n * nslots, 16), 256, 0, st>>>(
+                    qkv, qg, kg, c.norm_eps, e->rope_cos, e->rope_sin, kc, vc, n, c.num_heads, c.num_kv_heads, c.max_seq_len, start_pos);
+            else
+                qknorm_rope_kvwrite_kernel<64><<<ceil_div((long long)n * nslots, 32), 256, 0, st>>>(
+                    qkv, qg, kg, c.norm_eps, e->rope_cos, e->rope_sin, kc, vc, n, c.num_heads, c.num_kv_heads, c.max_seq_len, start_pos);
+            PGK_LAUNCH_CHECK();
+        }
+        if (pgk_status r = pgk_sdpa_causal(qkv, kc, vc, attn, c.num_heads, c.num_kv_heads, n, kv_len, D, 0.f, D, NQKV,
+                                           (int64_t)c.max_seq_len * D, D, D, QD, PGK_BF16, st))
+            return r;
+        if (pgk_status r = engine_gemm_nt(attn, L.w_o, (const bf16*)L.s_o, fp8, h32, true, n, H, QD, st)) return r;
+        rmsnorm_f32_bf16_kernel<<<ceil_div(n, 4), 256, 0, st>>>(h32, (const bf16*)L.mlp_norm, x, n, H, c.norm_eps);
+        PGK_LAUNCH_CHECK();
+        if (pgk_status r = engine_gemm_nt(x, L.w_gate_up, (const bf16*)L.s_gate_up, fp8, gu, false, n, 2 * I, H, st)) return r;
+        swiglu_rows_kernel<<<ceil_div((long long)n * I / 8, 256) > 2048 ? 2048 : ceil_div((long long)n * I / 8, 256), 256, 0, st>>>(gu, act, n, I);
+        PGK_LAUNCH_CHECK();
+        if (pgk_status r = engine_gemm_nt(act, L.w_down, (const bf16*)L.s_down, fp8, h32, true, n, H, I, st)) return r;
+    }
+    rmsnorm_f32_bf16_kernel<<<ceil_div(n, 4), 256, 0, st>>>(h32, e->final_norm, x, n, H, c.norm_eps);
+    PGK_LAUNCH_CHECK();
+    if (all_logits) {
+        if (pgk_status r = engine_gemm_nt(x, e->lm_head, nullptr, false, all_logits, false, n, c.vocab_size, H, st)) return r;
+    }
+    if (h_last_logits) {
+        // last row through the fp32-output GEMV (the decode lm_head kernel with a plain prologue)
+        float* xin = h32;  // reuse: widen the last normed row
+        bf16_rows_to_f32_kernel<<<4, 256, 0, st>>>(x + (size_t)(n - 1) * H, xin, H);
+        PGK_LAUNCH_CHECK();
+        FusedArgs a{};
+        a.w = e->lm_head; a.N = c.vocab_size; a.K = H; a.xin = xin;
+        a.out = e->logits + (size_t)seq * c.vocab_size; a.ld_out = c.vocab_size;
+        if (pgk_status r = launch_fused<bf16, float, 1, 4, PRO_PLAIN, EPI_STORE>(a, c.vocab_size, st)) return r;
+        PGK_CHECK_HIP(hipMemcpyAsync(h_last_logits, a.out, (size_t)c.vocab_size * 4, hipMemcpyDeviceToHost, st));
+        PGK_CHECK_HIP(hipStreamSynchronize(st));
+    }
+    return PGK_OK;
+}
+
+pgk_status pgk_engine_set_state(pgk_engine eh, const int32_t* h_tokens, const int32_t* h_positions, int batch, pgk_stream s) {
+    PGK_REQUIRE(eh && h_tokens && h_positions, "pgk_engine_set_state: null argument");
+    Engine* e = (Engine*)eh;
+    PGK_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch, "pgk_engine_set_state: batch %d outside [1,%d]", batch, e->cfg.max_batch);
+    for (int b = 0; b < batch; ++b) {
+        PGK_REQUIRE(h_tokens[b] >= 0 && h_tokens[b] < e->cfg.vocab_size, "pgk_engine_set_state: token %d out of range", h_tokens[b]);
+        PGK_REQUIRE(h_positions[b] >= 0 && h_positions[b] < e->cfg.max_seq_len, "pgk_engine_set_state: position %d outside cache of %d",
+                    h_positions[b], e->cfg.max_seq_len);
+    }
+    hipStream_t st = resolve_stream(s);
+    PGK_CHECK_HIP(hipMemcpyAsync(e->tokens, h_tokens, (size_t)batch * 4, hipMemcpyHostToDevice, st));
+    PGK_CHECK_HIP(hipMemcpyAsync(e->positions, h_positions, (size_t)batch * 4, hipMemcpyHostToDevice, st));
+    PGK_CHECK_HIP(hipStreamSynchronize(st));
+    return PGK_OK;
+}
+
+pgk_status pgk_engine_decode_step(pgk_engine eh, int batch, pgk_stream s) {
+    PGK_REQUIRE(eh, "pgk_engine_decode_step: null engine");
+    Engine* e = (Engine*)eh;
+    PGK_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch, "pgk_engine_decode_step: batch %d outside [1,%d]", batch, e->cfg.max_batch);
+    int launches = 0;
+    pgk_status r = decode_step(e, batch, resolve_stream(s), &launches);
+    e->launches_per_step = launches;
+    return r;
+}
+
+pgk_status pgk_engine_capture(pgk_engine eh, int batch, pgk_stream s) {
+    PGK_REQUIRE(eh, "pgk_engine_capture: null engine");
+    Engine* e = (Engine*)eh;
+    PGK_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch, "pgk_engine_capture: batch %d outside [1,%d]", batch, e->cfg.max_batch);
+    hipStream_t st = resolve_stream(s);
+    if (e->exec) { (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
+    if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+    PGK_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+    int launches = 0;
+    pgk_status r = decode_step(e, batch, st, &launches);
+    hipGraph_t g = nullptr;
+    hipError_t he = hipStreamEndCapture(st, &g);
+    if (r != PGK_OK) { if (g) (void)hipGraphDestroy(g); return r; }
+    if (he != hipSuccess || !g) return set_error(PGK_ERR_HIP, "pgk_engine_capture: hipStreamEndCapture: %s", hipGetErrorString(he));
+    e->graph = g;
+    PGK_CHECK_HIP(hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0));
+    e->graph_batch = batch;
+    e->launches_per_step = launches;
+    return PGK_OK;
+}
+
+pgk_status pgk_engine_replay(pgk_engine eh, int n_steps, pgk_stream s) {
+    PGK_REQUIRE(eh, "pgk_engine_replay: null engine");
+    Engine* e = (Engine*)eh;
+    PGK_REQUIRE(e->exec, "pgk_engine_replay: no captured graph (call pgk_engine_capture first)");
+    hipStream_t st = resolve_stream(s);
+    for (int i = 0; i < n_steps; ++i) PGK_CHECK_HIP(hipGraphLaunch(e->exec, st));
+    return PGK_OK;
+}
+
+pgk_status pgk_engine_logits_ptr(pgk_engine eh, void** logits_f32) {
+    PGK_REQUIRE(eh && logits_f32, "pgk_engine_logits_ptr: null argument");
+    *logits_f32 = ((Engine*)eh)->logits;
+    return PGK_OK;
+}
+
+pgk_status pgk_engine_read_tokens(pgk_engine eh, int32_t* h_out, int batch, int n_steps, pgk_stream s) {
+    PGK_REQUIRE(eh && h_out, "pgk_engine_read_tokens: null argument");
+    Engine* e = (Engine*)eh;
+    PGK_REQUIRE(n_steps >= 0 && n_steps <= e->log_cap, "pgk_engine_read_tokens: %d steps exceed the log capacity %d", n_steps, e->log_cap);
+    PGK_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch, "pgk_engine_read_tokens: bad batch %d", batch);
+    hipStream_t st = resolve_stream(s);
+    // log rows are max_batch wide; return the first `batch` columns, step-major
+    std::vector<int32_t> tmp((size_t)n_steps * e->cfg.max_batch);
+    if (n_steps) {
+        PGK_CHECK_HIP(hipMemcpyAsync(tmp.data(), e->token_log, tmp.size() * 4, hipMemcpyDeviceToHost, st));
+        PGK_CHECK_HIP(hipStreamSynchronize(st));
+    }
+    for (int t = 0; t < n_steps; ++t)
+        for (int b = 0; b < batch; ++b) h_out[(size_t)t * batch + b] = tmp[(size_t)t * e->cfg.max_batch + b];
+    return PGK_OK;
+}
+
+pgk_status pgk_engine_reset_log(pgk_engine eh, pgk_stream s) {
+    PGK_REQUIRE(eh, "pgk_engine_reset_log: null engine");
+    PGK_CHECK_HIP(hipMemsetAsync(((Engine*)eh)->step_counter, 0, 16, resolve_stream(s)));
+    return PGK_OK;
+}
+
+pgk_status pgk_engine_kv_ptr(pgk_engine eh, int layer, void** k, void** v) {
+    PGK_REQUIRE(eh && k && v, "pgk_engine_kv_ptr: null argument");
+    Engine* e = (Engine*)eh;
+    PGK_REQUIRE(layer >= 0 && layer < e->cfg.num_layers, "pgk_engine_kv_ptr: layer %d", layer);
+    *k = e->kcache + (size_t)layer * e->kv_layer_elems();
+    *v = e->vcache + (size_t)layer * e->kv_layer_elems();
+    return PGK_OK;
+}
+
+pgk_status pgk_engine_launches_per_step(pgk_engine eh, int* n) {
+    PGK_REQUIRE(eh && n, "pgk_engine_launches_per_step: null argument");
+    *n = ((Engine*)eh)->launches_per_step;
+    return PGK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,407 @@
+// MFMA GEMMs for gfx950 (prefill / batched projections):
+//   pgk_gemm_nt : C[M,N] = A[M,K] . W[N,K]^T (+bias)   - the Linear layer on the PyTorch-layout weight
+//   pgk_gemm_nn : C[M,N] = A[M,K] . B[K,N]             - the generic ops.matmul
+//   pgk_w8a16_gemm_kn : bf16 A, fp8-e4m3 B[K,N] with 128x128 block scales (reference K4 layout)
+//   (internal) nt with fp8 W[N,K] + block scales, used by the engine's fp8 prefill
+//
+// Structure (v1): BM x BN x 64 block tile, 256 threads = 2x2 waves, v_mfma_f32_16x16x32_{bf16,f16},
+// fp32 accumulate; A/B tiles staged global -> VGPR -> LDS (16-byte chunks, XOR-swizzled so the
+// ds_read_b128 fragment reads are bank-conflict free), two LDS buffers: the global loads of tile t+1
+// are issued before the MFMAs of tile t and written to LDS after them (one barrier per K tile).
+// The reference reaches for CUTLASS / cuBLASLt here (native/ops/matmul/matmul.cu:43-354); neither
+// exists on this target and nothing is linked in their place.
+
+#include "gemv_core.cuh"
+#include "pgk_internal.h"
+
+namespace pgk {
+
+template <class T> pgk_status launch_gemv(const T*, const T*, const T*, T*, int, int, int, hipStream_t);
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <class T> __device__ __forceinline__ f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c);
+template <> __device__ __forceinline__ f32x4_t mfma16<bf16>(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t mfma16<f16>(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+constexpr int GEMM_BK = 64;       // K elements per tile (128 bytes per LDS row)
+constexpr int GEMM_THREADS = 256;
+
+// byte offset of 16-byte chunk `kc` (0..7) of row `row` in a [rows][64 x 16-bit] swizzled LDS tile
+__device__ __forceinline__ int lds_off(int row, int kc) { return row * 128 + ((kc ^ (row & 7)) << 4); }
+
+enum BMode { B_NT = 0, B_NN = 1, B_NT_FP8 = 2, B_KN_FP8 = 3 };
+
+// ---- A-side (and NT B-side) tile: rows x 64 elements, k contiguous in memory -----------------
+template <int ROWS>
+struct TileRegsK {
+    static constexpr int CH = ROWS * 8 / GEMM_THREADS;  // 16-byte chunks per thread
+    uint4 v[CH > 0 ? CH : 1];
+    template <class T>
+    __device__ __forceinline__ void load(const T* base, int row0, int nrows, int k0, int K, int ld) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = threadIdx.x + i * GEMM_THREADS;
+            const int r = c >> 3, kc = c & 7;
+            const int gr = row0 + r, gk = k0 + kc * 8;
+            if (gr < nrows && gk < K) v[i] = *reinterpret_cast<const uint4*>(base + (size_t)gr * ld + gk);
+            else v[i] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void store(char* lds) const {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = threadIdx.x + i * GEMM_THREADS;
+            *reinterpret_cast<uint4*>(lds + lds_off(c >> 3, c & 7)) = v[i];
+        }
+    }
+};
+
+// ---- NN B-side tile: B[K,N] row-major; tile is 64 k-rows x BN columns, transposed into LDS ----
+template <int BN>
+struct TileRegsN {
+    static constexpr int CH = 64 * (BN / 8) / GEMM_THREADS;
+    uint4 v[CH];
+    template <class T>
+    __device__ __forceinline__ void load(const T* base, int n0, int N, int k0, int K) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = threadIdx.x + i * GEMM_THREADS;
+            const int k = c / (BN / 8), nc = c % (BN / 8);
+            const int gk = k0 + k, gn = n0 + nc * 8;
+            if (gk < K && gn < N) v[i] = *reinterpret_cast<const uint4*>(base + (size_t)gk * N + gn);  // N % 8 == 0
+            else v[i] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void store(char* lds) const {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = threadIdx.x + i * GEMM_THREADS;
+            const int k = c / (BN / 8), nc = c % (BN / 8);
+            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = nc * 8 + j;
+                const uint16_t e = (uint16_t)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xFFFFu));
+                *reinterpret_cast<uint16_t*>(lds + lds_off(n, k >> 3) + (k & 7) * 2) = e;
+            }
+        }
+    }
+};
+
+// ---- fp8 B tiles, dequantised to bf16 on the way into LDS -----------------------------------
+// NT: W[N,K] u8, scale[N/128, K/128] bf16.  One 16-byte load = 16 k-values of one row.
+template <int BN>
+struct TileRegsFp8NT {
+    static constexpr int CH = (BN * 4 + GEMM_THREADS - 1) / GEMM_THREADS;  // 4 x 16-code chunks per row
+    uint4 v[CH];
+    float sc[CH];
+    __device__ __forceinline__ void load(const uint8_t* w, const bf16* scale, int n0, int N, int k0, int K) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = threadIdx.x + i * GEMM_THREADS;
+            const int r = c >> 2, q = c & 3;
+            const int gn = n0 + r, gk = k0 + q * 16;
+            if (c < BN * 4 && gn < N && gk < K) {
+                v[i] = *reinterpret_cast<const uint4*>(w + (size_t)gn * K + gk);
+                sc[i] = to_f(scale[(size_t)(gn >> 7) * (K >> 7) + (gk >> 7)]);
+            } else {
+                v[i] = make_uint4(0, 0, 0, 0);
+                sc[i] = 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(char* lds) const {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = threadIdx.x + i * GEMM_THREADS;
+            if (c >= BN * 4) continue;
+            const int r = c >> 2, q = c & 3;
+            float f[16];
+            WTraits<fp8e4m3>::decode(v[i], f);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint4 o = make_uint4(pack_bf16x2(f[8 * h] * sc[i], f[8 * h + 1] * sc[i]),
+                                           pack_bf16x2(f[8 * h + 2] * sc[i], f[8 * h + 3] * sc[i]),
+                                           pack_bf16x2(f[8 * h + 4] * sc[i], f[8 * h + 5] * sc[i]),
+                                           pack_bf16x2(f[8 * h + 6] * sc[i], f[8 * h + 7] * sc[i]));
+                *reinterpret_cast<uint4*>(lds + lds_off(r, q * 2 + h)) = o;
+            }
+        }
+    }
+};
+// KN: B[K,N] u8, scale[K/128, N/128].  One 16-byte load = 16 n-values of one k.
+template <int BN>
+struct TileRegsFp8KN {
+    static constexpr int PER_ROW = BN / 16;
+    static constexpr int CH = (64 * PER_ROW + GEMM_THREADS - 1) / GEMM_THREADS;
+    uint4 v[CH];
+    float sc[CH];
+    __device__ __forceinline__ void load(const uint8_t* b, const bf16* scale, int n0, int N, int k0, int K) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = threadIdx.x + i * GEMM_THREADS;
+            const int k = c / PER_ROW, nc = c % PER_ROW;
+            const int gk = k0 + k, gn = n0 + nc * 16;
+            if (c < 64 * PER_ROW && gk < K && gn < N) {
+                v[i] = *reinterpret_cast<const uint4*>(b + (size_t)gk * N + gn);  // N % 16 == 0
+                sc[i] = to_f(scale[(size_t)(gk >> 7) * (N >> 7) + (gn >> 7)]);
+            } else {
+                v[i] = make_uint4(0, 0, 0, 0);
+                sc[i] = 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(char* lds) const {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = threadIdx.x + i * GEMM_THREADS;
+            if (c >= 64 * PER_ROW) continue;
+            const int k = c / PER_ROW, nc = c % PER_ROW;
+            float f[16];
+            WTraits<fp8e4m3>::decode(v[i], f);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int n = nc * 16 + j;
+                *reinterpret_cast<uint16_t*>(lds + lds_off(n, k >> 3) + (k & 7) * 2) = f_to_bf16_bits(f[j] * sc[i]);
+            }
+        }
+    }
+};
+
+template <class T, int BM, int BN, int MODE, int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(const T* A, const void* Bv, const bf16* bscale,
+                                                                const T* bias, void* Cv, int M, int N, int K) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto As = [&](int buf) -> char* { return smem + buf * A_BYTES; };
+    auto Bs = [&](int buf) -> char* { return smem + 2 * A_BYTES + buf * B_BYTES; };
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    TileRegsK<BM> ra;
+    TileRegsK<BN> rb_nt;
+    TileRegsN<BN> rb_nn;
+    TileRegsFp8NT<BN> rb_f8nt;
+    TileRegsFp8KN<BN> rb_f8kn;
+
+    auto load_tiles = [&](int k0) {
+        ra.load(A, m0, M, k0, K, K);
+        if constexpr (MODE == B_NT) rb_nt.load((const T*)Bv, n0, N, k0, K, K);
+        else if constexpr (MODE == B_NN) rb_nn.load((const T*)Bv, n0, N, k0, K);
+        else if constexpr (MODE == B_NT_FP8) rb_f8nt.load((const uint8_t*)Bv, bscale, n0, N, k0, K);
+        else rb_f8kn.load((const uint8_t*)Bv, bscale, n0, N, k0, K);
+    };
+    auto store_tiles = [&](int buf) {
+        ra.store(As(buf));
+        if constexpr (MODE == B_NT) rb_nt.store(Bs(buf));
+        else if constexpr (MODE == B_NN) rb_nn.store(Bs(buf));
+        else if constexpr (MODE == B_NT_FP8) rb_f8nt.store(Bs(buf));
+        else rb_f8kn.store(Bs(buf));
+    };
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (K + GEMM_BK - 1) / GEMM_BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles((kt + 1) * GEMM_BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 fa[TM], fb[TN];
+            const int kc = ks * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const uint4*>(As(buf) + lds_off(wm * WM + i * 16 + (lane & 15), kc));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const uint4*>(Bs(buf) + lds_off(wn * WN + j * 16 + (lane & 15), kc));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma16<T>(fa[i], fb[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // C/D map of v_mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 16 + (lane & 15);
+            if (col >= N) continue;
+            const float b = bias ? to_f(bias[col]) : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+                if (row >= M) continue;
+                if constexpr (EPI == 0) reinterpret_cast<T*>(Cv)[(size_t)row * N + col] = from_f<T>(acc[i][j][r] + b);
+                else reinterpret_cast<float*>(Cv)[(size_t)row * N + col] += acc[i][j][r] + b;  // fp32 residual stream
+            }
+        }
+}
+
+// fp32 (and odd-shape) fallback: 64x64 tile, 16x16 threads x 4x4 outputs, LDS-staged.
+template <class T, bool B_IS_NT>
+__global__ __launch_bounds__(256) void gemm_simple_kernel(const T* A, const T* B, const T* bias, T* C, int M, int N, int K) {
+    __shared__ float As[16][64 + 1];
+    __shared__ float Bs[16][64 + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+            const int r = i >> 4, k = i & 15;  // r: row in tile, k: k index
+            const int gm = m0 + r, gn = n0 + r, gk = k0 + k;
+            As[k][r] = (gm < M && gk < K) ? to_f(A[(size_t)gm * K + gk]) : 0.f;
+            if (B_IS_NT) Bs[k][r] = (gn < N && gk < K) ? to_f(B[(size_t)gn * K + gk]) : 0.f;
+        }
+        if (!B_IS_NT) {
+            for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+                const int k = i >> 6, c = i & 63;
+                const int gk = k0 + k, gn = n0 + c;
+                Bs[k][c] = (gk < K && gn < N) ? to_f(B[(size_t)gk * N + gn]) : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; b[i] = Bs[k][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gm = m0 + ty * 4 + i, gn = n0 + tx * 4 + j;
+            if (gm < M && gn < N) C[(size_t)gm * N + gn] = from_f<T>(acc[i][j] + (bias ? to_f(bias[gn]) : 0.f));
+        }
+}
+
+template <class T, int BM, int BN, int MODE, int EPI>
+static pgk_status launch_mfma(const T* A, const void* B, const bf16* bscale, const T* bias, void* C, int M, int N, int K,
+                              hipStream_t st) {
+    constexpr size_t LDS = 2 * (size_t)(BM + BN) * 128;
+    static bool attr_done = false;
+    if (LDS > 48 * 1024 && !attr_done) {
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<T, BM, BN, MODE, EPI>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        attr_done = true;
+    }
+    dim3 grid(ceil_div(N, BN), ceil_div(M, BM));
+    gemm_mfma_kernel<T, BM, BN, MODE, EPI><<<grid, GEMM_THREADS, LDS, st>>>(A, B, bscale, bias, C, M, N, K);
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
+}
+
+// Tile choice: smallest BM covering M (<=128); BN as large as keeps >= ~256 workgroups in flight.
+template <class T, int MODE, int EPI = 0>
+static pgk_status dispatch_mfma(const T* A, const void* B, const bf16* bscale, const T* bias, void* C, int M, int N, int K,
+                                hipStream_t st) {
+    const int bm = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
+    const long long mblocks = (M + bm - 1) / bm;
+    int bn = 128;
+    while (bn > 32 && mblocks * ((N + bn - 1) / bn) < 256) bn >>= 1;
+    if (MODE == B_KN_FP8 && bn < 64) bn = 64;  // keep whole 16-code chunks per thread
+#define PGK_TILE(BM_, BN_) if (bm == BM_ && bn == BN_) return launch_mfma<T, BM_, BN_, MODE, EPI>(A, B, bscale, bias, C, M, N, K, st);
+    PGK_TILE(128, 128) PGK_TILE(128, 64) PGK_TILE(128, 32)
+    PGK_TILE(64, 128) PGK_TILE(64, 64) PGK_TILE(64, 32)
+    PGK_TILE(32, 128) PGK_TILE(32, 64) PGK_TILE(32, 32)
+#undef PGK_TILE
+    return set_error(PGK_ERR_INVALID, "gemm: no tile for bm=%d bn=%d", bm, bn);
+}
+
+// internal (engine prefill): bf16 A against a bf16 or fp8 (+128x128 bf16 block scales) weight W[N,K];
+// either a bf16 result or an fp32 "+=" into the residual stream.
+pgk_status engine_gemm_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, void* C, bool accum_f32, int M,
+                          int N, int K, hipStream_t st) {
+    if (fp8) {
+        if (accum_f32) return dispatch_mfma<bf16, B_NT_FP8, 1>(A, W, wscale, nullptr, C, M, N, K, st);
+        return dispatch_mfma<bf16, B_NT_FP8, 0>(A, W, wscale, nullptr, C, M, N, K, st);
+    }
+    if (accum_f32) return dispatch_mfma<bf16, B_NT, 1>(A, W, nullptr, nullptr, C, M, N, K, st);
+    return dispatch_mfma<bf16, B_NT, 0>(A, W, nullptr, nullptr, C, M, N, K, st);
+}
+
+}  // namespace pgk
+
+using namespace pgk;
+
+extern "C" {
+
+pgk_status pgk_gemm_nt(const void* a, const void* w, const void* bias, void* c, int m, int n, int k, pgk_dtype dt,
+                       pgk_stream s) {
+    PGK_REQUIRE(a && w && c, "pgk_gemm_nt: null pointer");
+    PGK_REQUIRE(m >= 0 && n > 0 && k > 0, "pgk_gemm_nt: bad shape M=%d N=%d K=%d", m, n, k);
+    if (!m) return PGK_OK;
+    hipStream_t st = resolve_stream(s);
+    const bool al = aligned16(a) && aligned16(w) && (k % 8 == 0);
+    if (dt == PGK_F32 || !al) {
+        if (m <= 8) {
+            PGK_DISPATCH_FLOAT(dt, "pgk_gemm_nt", return (launch_gemv<T>((const T*)a, (const T*)w, (const T*)bias, (T*)c, m, k, n, st)));
+        }
+        dim3 grid(ceil_div(n, 64), ceil_div(m, 64));
+        PGK_DISPATCH_FLOAT(dt, "pgk_gemm_nt", (gemm_simple_kernel<T, true><<<grid, 256, 0, st>>>((const T*)a, (const T*)w, (const T*)bias, (T*)c, m, n, k)));
+        PGK_LAUNCH_CHECK();
+        return PGK_OK;
+    }
+    if (m <= 8 && (size_t)m * k * 2 <= 64 * 1024) {  // weight-streaming GEMV path
+        if (dt == PGK_BF16) return launch_gemv<bf16>((const bf16*)a, (const bf16*)w, (const bf16*)bias, (bf16*)c, m, k, n, st);
+        return launch_gemv<f16>((const f16*)a, (const f16*)w, (const f16*)bias, (f16*)c, m, k, n, st);
+    }
+    if (dt == PGK_BF16) return dispatch_mfma<bf16, B_NT>((const bf16*)a, w, nullptr, (const bf16*)bias, (bf16*)c, m, n, k, st);
+    return dispatch_mfma<f16, B_NT>((const f16*)a, w, nullptr, (const f16*)bias, (f16*)c, m, n, k, st);
+}
+
+pgk_status pgk_gemm_nn(const void* a, const void* b, void* c, int m, int n, int k, pgk_dtype dt, pgk_stream s) {
+    PGK_REQUIRE(a && b && c, "pgk_gemm_nn: null pointer");
+    PGK_REQUIRE(m >= 0 && n > 0 && k > 0, "pgk_gemm_nn: bad shape M=%d N=%d K=%d", m, n, k);
+    if (!m) return PGK_OK;
+    hipStream_t st = resolve_stream(s);
+    const bool al = aligned16(a) && aligned16(b) && (k % 8 == 0) && (n % 8 == 0);
+    if (dt == PGK_F32 || !al) {
+        dim3 grid(ceil_div(n, 64), ceil_div(m, 64));
+        PGK_DISPATCH_FLOAT(dt, "pgk_gemm_nn", (gemm_simple_kernel<T, false><<<grid, 256, 0, st>>>((const T*)a, (const T*)b, nullptr, (T*)c, m, n, k)));
+        PGK_LAUNCH_CHECK();
+        return PGK_OK;
+    }
+    if (dt == PGK_BF16) return dispatch_mfma<bf16, B_NN>((const bf16*)a, b, nullptr, nullptr, (bf16*)c, m, n, k, st);
+    return dispatch_mfma<f16, B_NN>((const f16*)a, b, nullptr, nullptr, (f16*)c, m, n, k, st);
+}
+
+pgk_status pgk_w8a16_gemm_kn(const void* a, const uint8_t* b_kn, const void* scale, void* c, int m, int n, int k,
+                             pgk_stream s) {
+    PGK_REQUIRE(a && b_kn && scale && c, "pgk_w8a16_gemm_kn: null pointer");
+    PGK_REQUIRE(m >= 0 && n > 0 && k > 0, "pgk_w8a16_gemm_kn: bad shape M=%d N=%d K=%d", m, n, k);
+    PGK_REQUIRE(k % 128 == 0 && n % 128 == 0, "pgk_w8a16_gemm_kn: K=%d, N=%d must be multiples of the 128x128 scale block", k, n);
+    PGK_REQUIRE(aligned16(a) && aligned16(b_kn), "pgk_w8a16_gemm_kn: operands must be 16-byte aligned");
+    if (!m) return PGK_OK;
+    return dispatch_mfma<bf16, B_KN_FP8>((const bf16*)a, b_kn, (const bf16*)scale, nullptr, (bf16*)c, m, n, k, resolve_stream(s));
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// Device-side helpers for gfx950 (CDNA4): 64-lane wavefronts, 16-byte vector access,
+// bf16/f16 <-> fp32 conversion, wave/block reductions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace pgk {
+
+constexpr int WAVE = 64;
+
+struct bf16 { uint16_t bits; };
+struct f16 { _Float16 v; };
+
+// ---- scalar conversions -------------------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+// RNE; NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950).
+__device__ __forceinline__ uint16_t f_to_bf16_bits(float f) {
+    __bf16 b = static_cast<__bf16>(f);
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return static_cast<uint32_t>(f_to_bf16_bits(lo)) | (static_cast<uint32_t>(f_to_bf16_bits(hi)) << 16);
+}
+
+template <class T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<f16>(f16 v) { return static_cast<float>(v.v); }
+template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return bf16_bits_to_f(v.bits); }
+
+template <class T> __device__ __forceinline__ T from_f(float f);
+template <> __device__ __forceinline__ float from_f<float>(float f) { return f; }
+template <> __device__ __forceinline__ f16 from_f<f16>(float f) { return f16{static_cast<_Float16>(f)}; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float f) { return bf16{f_to_bf16_bits(f)}; }
+
+// ---- 16-byte vectors ----------------------------------------------------------------------
+// Vec<T>::N elements of T in one 16-byte access: 4 x fp32 or 8 x 16-bit.
+template <class T> struct Vec {
+    static constexpr int N = 16 / sizeof(T);
+    uint4 raw;
+    __device__ __forceinline__ void load(const T* p) { raw = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void store(T* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+    __device__ __forceinline__ void to_float(float (&f)[N]) const;
+    __device__ __forceinline__ void from_float(const float (&f)[N]);
+};
+
+template <> __device__ __forceinline__ void Vec<float>::to_float(float (&f)[4]) const {
+    f[0] = __uint_as_float(raw.x); f[1] = __uint_as_float(raw.y);
+    f[2] = __uint_as_float(raw.z); f[3] = __uint_as_float(raw.w);
+}
+template <> __device__ __forceinline__ void Vec<float>::from_float(const float (&f)[4]) {
+    raw = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+template <> __device__ __forceinline__ void Vec<bf16>::to_float(float (&f)[8]) const {
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(w[i] << 16);
+        f[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+    }
+}
+template <> __device__ __forceinline__ void Vec<bf16>::from_float(const float (&f)[8]) {
+    raw = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                     pack_bf16x2(f[6], f[7]));
+}
+template <> __device__ __forceinline__ void Vec<f16>::to_float(float (&f)[8]) const {
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(w[i] & 0xFFFFu)));
+        f[2 * i + 1] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(w[i] >> 16)));
+    }
+}
+template <> __device__ __forceinline__ void Vec<f16>::from_float(const float (&f)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t lo = __builtin_bit_cast(uint16_t, static_cast<_Float16>(f[2 * i]));
+        const uint32_t hi = __builtin_bit_cast(uint16_t, static_cast<_Float16>(f[2 * i + 1]));
+        w[i] = lo | (hi << 16);
+    }
+    raw = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---- reductions ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+// Sum over the 16 lanes that share (lane >> 4).
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+
+// Block-wide sum for blocks of up to 1024 threads (16 waves); `scratch` holds >= 16 floats.
+// Every thread gets the result.  Two barriers.
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    if (nw == 1) return v;
+    __syncthreads();  // scratch may still be read from a previous call
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += scratch[i];
+    return t;
+}
+
+}  // namespace pgk

@@ -1,0 +1,442 @@
+"""GPU parity tests for the op surface: HIP kernels (through the C ABI) vs the CPU oracle and the
+golden vectors generated from the reference.  Tolerances: fp32 ops ~1e-5 (summation order only);
+bf16 <= 1e-2 relative L2 error (BASELINE.json / reference tests/test_gemv_correctness.py:144-149);
+fp8 <= 5e-2; copies and index ops bit-exact."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as O
+from tests.conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+pk = pytest.importorskip("pygpukit_amd")
+from pygpukit_amd import ops  # noqa: E402
+from pygpukit_amd.core import bfloat16, float16, float32, from_numpy  # noqa: E402
+
+g1 = load_golden("g1_ops.npz")
+DT = {"float32": float32, "float16": float16, "bfloat16": bfloat16}
+TOL = {"float32": 2e-5, "float16": 2e-3, "bfloat16": 1e-2}
+
+
+def dev(x: np.ndarray, dt: str = "float32"):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if dt == "float32":
+        return from_numpy(x)
+    if dt == "float16":
+        return from_numpy(x.astype(np.float16))
+    return from_numpy(O.f32_to_bf16_bits(x).reshape(x.shape))
+
+
+def host(a) -> np.ndarray:
+    h = a.to_numpy()
+    if a.dtype == bfloat16:
+        return O.bf16_bits_to_f32(h)
+    return h.astype(np.float32)
+
+
+def rounded(x: np.ndarray, dt: str) -> np.ndarray:
+    """The value the device actually holds for x in dtype dt."""
+    if dt == "bfloat16":
+        return O.bf16_round(x)
+    if dt == "float16":
+        return x.astype(np.float16).astype(np.float32)
+    return x.astype(np.float32)
+
+
+def close(a, ref, dt):
+    e = rel_err(a, ref)
+    assert e <= TOL[dt], f"rel err {e:.3e} > {TOL[dt]} ({dt})"
+
+
+# ----------------------------------------------------------------------------- runtime
+def test_device_is_mi355x_and_pool_works():
+    b = pk.get_backend()
+    assert b.is_available()
+    props = b.get_device_properties(0)
+    assert props["wavefront_size"] == 64
+    s0 = b.pool_stats()
+    a = pk.zeros((1000,), "float32")
+    p = a.data_ptr()
+    del a
+    a2 = pk.zeros((1000,), "float32")  # same size class -> served from the free list
+    s1 = b.pool_stats()
+    assert a2.data_ptr() == p
+    assert s1["n_pool_hit"] >= s0["n_pool_hit"] + 1
+
+
+def test_roundtrip_and_views():
+    x = np.arange(24, dtype=np.float32).reshape(4, 6)
+    a = from_numpy(x)
+    np.testing.assert_array_equal(a.to_numpy(), x)
+    np.testing.assert_array_equal(pk.ones((3, 2), "bfloat16").astype(float32).to_numpy(), np.ones((3, 2), np.float32))
+    row = from_numpy(x[:1])
+    v = row.narrow(2, 3)
+    np.testing.assert_array_equal(v.to_numpy(), x[:1, 2:5])
+    np.testing.assert_array_equal(a.view((6, 4)).to_numpy(), x.reshape(6, 4))
+    np.testing.assert_array_equal(a.slice_rows(2).to_numpy(), x[:2])
+    np.testing.assert_array_equal(a.T.to_numpy(), x.T)
+    np.testing.assert_array_equal(a.reshape(-1, 8).to_numpy(), x.reshape(-1, 8))
+    np.testing.assert_array_equal(a[1:3, ::2].to_numpy(), x[1:3, ::2])
+    np.testing.assert_array_equal(a.clone().to_numpy(), x)
+    with pytest.raises(ValueError):
+        a.view((5, 5))
+    # bf16 RNE on the device == reference formula (golden bits)
+    v = g1["bf16_in"][:1000]
+    np.testing.assert_array_equal(from_numpy(v).astype(bfloat16).to_numpy(), g1["bf16_bits"][:1000])
+
+
+# ----------------------------------------------------------------------------- elementwise
+@pytest.mark.parametrize("dt", ["float32", "float16", "bfloat16"])
+def test_binary_and_inplace(dt):
+    rng = np.random.default_rng(0)
+    for n in (1, 7, 1024, 4099):
+        a, b = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32) + 3.0
+        ar, br = rounded(a, dt), rounded(b, dt)
+        A, B = dev(a, dt), dev(b, dt)
+        close(host(ops.add(A, B)), ar + br, dt)
+        close(host(ops.sub(A, B)), ar - br, dt)
+        close(host(ops.mul(A, B)), ar * br, dt)
+        close(host(ops.div(A, B)), ar / br, dt)
+        ops.add_inplace(A, B)
+        close(host(A), ar + br, dt)
+        ops.mul_inplace(B, B)
+        close(host(B), br * br, dt)
+    with pytest.raises(ValueError):
+        ops.add(dev(np.zeros(3)), dev(np.zeros(4)))
+
+
+def test_elementwise_golden_fp32():
+    x = g1["act_x"]
+    np.testing.assert_allclose(host(ops.silu(dev(x))), g1["silu"], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(host(ops.gelu(dev(x))), g1["gelu"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_array_equal(host(ops.add(dev(x), dev(x[::-1].copy()))), g1["add"])
+    np.testing.assert_array_equal(host(ops.mul(dev(x), dev(x[::-1].copy()))), g1["mul"])
+
+
+@pytest.mark.parametrize("dt", ["float32", "bfloat16"])
+def test_activations_glu_bias_cast(dt):
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal((5, 264)) * 2).astype(np.float32)
+    u = rng.standard_normal((5, 264)).astype(np.float32)
+    xr, ur = rounded(x, dt), rounded(u, dt)
+    close(host(ops.silu(dev(x, dt))), O.silu(xr), dt)
+    close(host(ops.gelu(dev(x, dt))), O.gelu(xr), dt)
+    close(host(ops.swiglu(dev(x, dt), dev(u, dt))), O.swiglu(xr, ur), dt)
+    X = dev(x, dt)
+    ops.silu(X, out=X)  # in place
+    close(host(X), O.silu(xr), dt)
+    b = rng.standard_normal(264).astype(np.float32)
+    Y = dev(x, dt)
+    ops.bias_add_inplace(Y, dev(b, dt))
+    close(host(Y), xr + rounded(b, dt), dt)
+    if dt == "float32":
+        np.testing.assert_array_equal(ops.cast_f32_to_bf16(dev(x)).to_numpy(), O.f32_to_bf16_bits(x))
+        np.testing.assert_array_equal(host(ops.cast_bf16_to_f32(dev(x, "bfloat16"))), O.bf16_round(x))
+        np.testing.assert_array_equal(ops.cast_f32_to_f16(dev(x)).to_numpy(), x.astype(np.float16))
+
+
+# ----------------------------------------------------------------------------- norms / rope
+def test_norms_golden_fp32():
+    x, g, b = g1["norm_x"], g1["norm_g"], g1["norm_b"]
+    np.testing.assert_allclose(host(ops.rmsnorm(dev(x), dev(g), 1e-6)), g1["rmsnorm_1e6"], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(host(ops.rmsnorm(dev(x), dev(g), 1e-5)), g1["rmsnorm_1e5"], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(host(ops.layernorm(dev(x), dev(g), dev(b), 1e-5)), g1["layernorm_1e5"], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("dt", ["float32", "bfloat16"])
+@pytest.mark.parametrize("shape", [(1, 1024), (16, 128), (3, 4096), (2, 5000), (5, 100)])
+def test_rmsnorm_shapes(dt, shape):
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(shape).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(shape[1])).astype(np.float32)
+    r = rng.standard_normal(shape).astype(np.float32)
+    xr, gr, rr = rounded(x, dt), rounded(g, dt), rounded(r, dt)
+    close(host(ops.rmsnorm(dev(x, dt), dev(g, dt), 1e-6)), O.rmsnorm(xr, gr, 1e-6), dt)
+    close(host(ops.rmsnorm_residual(dev(x, dt), dev(r, dt), dev(g, dt), 1e-6)), O.rmsnorm_residual(xr, rr, gr, 1e-6), dt)
+    out = dev(np.zeros(shape), dt)
+    ops.rmsnorm(dev(x, dt), dev(g, dt), 1e-6, out=out)
+    close(host(out), O.rmsnorm(xr, gr, 1e-6), dt)
+
+
+def test_rope_golden_and_bf16():
+    pos = g1["rope_pos"]
+    cos, sin = g1["rope_cos_tab"][pos], g1["rope_sin_tab"][pos]
+    q, k = dev(g1["rope_q"]), dev(g1["rope_k"])
+    ops.rope_inplace(q, k, dev(cos), dev(sin))
+    np.testing.assert_allclose(host(q), g1["rope_q_out"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(host(k), g1["rope_k_out"], rtol=1e-6, atol=1e-6)
+    qb, kb = dev(g1["rope_q"], "bfloat16"), dev(g1["rope_k"], "bfloat16")
+    ops.rope_inplace_f32table(qb, kb, dev(cos), dev(sin))
+    qr, kr = O.rope(O.bf16_round(g1["rope_q"]), O.bf16_round(g1["rope_k"]), cos, sin)
+    close(host(qb), qr, "bfloat16")
+    close(host(kb), kr, "bfloat16")
+
+
+# ----------------------------------------------------------------------------- byte movers
+def test_shuffles_bit_exact():
+    t = g1["shuffle_in"]
+    np.testing.assert_array_equal(ops.repeat_interleave_axis1(dev(t), 3).to_numpy(), g1["repeat_interleave_3"])
+    np.testing.assert_array_equal(ops.transpose_3d_021(dev(t)).to_numpy(), g1["transpose_3d_021"])
+    np.testing.assert_array_equal(ops.concat_axis0(dev(t), dev(t[:2].copy())).to_numpy(), g1["concat_axis0"])
+    np.testing.assert_array_equal(ops.transpose(dev(g1["transpose_in"])).to_numpy(), g1["transpose_out"])
+    rng = np.random.default_rng(3)
+    for shape in [(1, 1), (65, 130), (300, 77), (128, 1024)]:
+        x = rng.integers(0, 60000, shape).astype(np.uint16)
+        np.testing.assert_array_equal(ops.transpose(from_numpy(x)).to_numpy(), x.T)
+        xb = rng.integers(0, 255, shape).astype(np.uint8)
+        np.testing.assert_array_equal(ops.transpose(from_numpy(xb)).to_numpy(), xb.T)
+    x3 = rng.integers(0, 60000, (5, 7, 24)).astype(np.uint16)
+    np.testing.assert_array_equal(ops.transpose_3d_021(from_numpy(x3)).to_numpy(), x3.transpose(1, 0, 2))
+    np.testing.assert_array_equal(ops.reshape_copy(from_numpy(x3), (35, 24)).to_numpy(), x3.reshape(35, 24))
+    qkv = rng.integers(0, 60000, (6, 32 + 16 + 16)).astype(np.uint16)
+    q, k, v = pk.empty((6, 32), "bfloat16"), pk.empty((6, 16), "bfloat16"), pk.empty((6, 16), "bfloat16")
+    ops.split_qkv_batch(from_numpy(qkv), q, k, v, 32, 16, 16)
+    np.testing.assert_array_equal(q.to_numpy(), qkv[:, :32])
+    np.testing.assert_array_equal(k.to_numpy(), qkv[:, 32:48])
+    np.testing.assert_array_equal(v.to_numpy(), qkv[:, 48:])
+
+
+def test_embedding_and_kv_cache():
+    rng = np.random.default_rng(4)
+    E = rng.integers(0, 60000, (50, 96)).astype(np.uint16)
+    Ed = from_numpy(E)
+    out = pk.empty((1, 96), "bfloat16")
+    ops.embedding_lookup(Ed, out, 17)
+    np.testing.assert_array_equal(out.to_numpy(), E[17:18])
+    ops.embedding_lookup_ptr(Ed, out, from_numpy(np.array([33], np.int32)))
+    np.testing.assert_array_equal(out.to_numpy(), E[33:34])
+    ids = np.array([3, 49, 0, 7], np.int32)
+    outb = pk.empty((4, 96), "bfloat16")
+    ops.embedding_lookup_batch(Ed, outb, from_numpy(ids), 4)
+    np.testing.assert_array_equal(outb.to_numpy(), E[ids])
+    sl = pk.empty((3, 96), "bfloat16")
+    ops.slice_rows_range_ptr(Ed, sl, from_numpy(np.array([10], np.int32)), 3)
+    np.testing.assert_array_equal(sl.to_numpy(), E[10:13])
+    with pytest.raises(ValueError):
+        ops.embedding_lookup(Ed, out, 50)
+    # KV cache: expanded (reference layout) and un-expanded
+    Hq, Hkv, D, MAX = 4, 2, 32, 16
+    for hc in (Hq, Hkv):
+        cache = np.zeros((hc, MAX, D), np.float32)
+        cd = from_numpy(cache)
+        new1 = rng.standard_normal((1, Hkv, D)).astype(np.float32)
+        ops.kv_cache_update_gqa(from_numpy(new1), cd, Hq, 5)
+        O.kv_cache_update_gqa(new1, cache, Hq, 5)
+        new2 = rng.standard_normal((1, Hkv, D)).astype(np.float32)
+        ops.kv_cache_update_gqa_ptr(from_numpy(new2), cd, Hq, from_numpy(np.array([6], np.int32)))
+        O.kv_cache_update_gqa(new2, cache, Hq, 6)
+        new3 = rng.standard_normal((4, Hkv, D)).astype(np.float32)
+        ops.kv_cache_prefill_gqa(from_numpy(new3), cd, Hq, 8)
+        O.kv_cache_prefill_gqa(new3, cache, Hq, 8)
+        np.testing.assert_array_equal(cd.to_numpy(), cache)
+        with pytest.raises(ValueError):
+            ops.kv_cache_update_gqa(from_numpy(new1), cd, Hq, MAX)
+
+
+def test_argmax_lowest_index_ties():
+    lg = g1["sample_logits"].copy()
+    for r, want in zip(lg, g1["sample_t0"]):
+        assert ops.sample_greedy(dev(r)) == int(want)
+        assert ops.sample_greedy(dev(r, "bfloat16")) == int(np.argmax(O.bf16_round(r)))
+    big = np.zeros(151936, np.float32)
+    big[[150000, 70000, 1234]] = 5.0
+    assert ops.argmax(dev(big)) == 1234
+    rows = ops.argmax_rows(dev(lg)).to_numpy()
+    np.testing.assert_array_equal(rows, np.argmax(lg, axis=1))
+    assert ops.sample_token_gpu(dev(lg[0]), 0.0, 0, 1.0) == int(np.argmax(lg[0]))
+
+
+# ----------------------------------------------------------------------------- GEMV / GEMM
+@pytest.mark.parametrize("dt", ["bfloat16", "float16", "float32"])
+@pytest.mark.parametrize("kn", [(1024, 4096), (2048, 1024), (3072, 1024), (1024, 6144), (100, 37), (4096, 130)])
+def test_gemv(dt, kn):
+    K, N = kn
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal(K).astype(np.float32)
+    b = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    ref = (rounded(b, dt).astype(np.float64) @ rounded(a, dt).astype(np.float64)).astype(np.float32)
+    A, B = dev(a, dt), dev(b, dt)
+    if dt == "bfloat16":
+        c = ops.gemv_bf16(A, B)
+        out = pk.empty((N,), "bfloat16")
+        ops.gemv_bf16(A, B, out=out)
+        np.testing.assert_array_equal(out.to_numpy(), c.to_numpy())
+    else:
+        c = ops.matmul_nt(A.view((1, K)), B).view((N,))
+    close(host(c), ref, dt)
+
+
+def test_gemv_bf16_vs_unrounded_fp32_reference_bar():
+    """The reference's own check: bf16 GEMV vs fp32 matmul of the UNROUNDED inputs, rel err < 1e-2."""
+    rng = np.random.default_rng(6)
+    K, N = 2048, 8192
+    a, b = rng.standard_normal(K).astype(np.float32), rng.standard_normal((N, K)).astype(np.float32)
+    c = host(ops.gemv_bf16(dev(a, "bfloat16"), dev(b, "bfloat16")))
+    assert rel_err(c, b @ a) < 1e-2
+
+
+def test_fp8_hardware_decode_matches_reference_table():
+    """Every finite E4M3 code through the GEMV kernel == the reference LUT (quant.py:292-320)."""
+    table = O.fp8_e4m3_table()
+    codes = np.array([c for c in range(256) if c not in (0x7F, 0xFF)], np.uint8)
+    K = N = 256
+    W = np.zeros((N, K), np.uint8)
+    for i, c in enumerate(codes):
+        W[i, i] = c  # row i picks code c against a one-hot... use identity activation instead
+    scale = O.f32_to_bf16_bits(np.ones((2, 2), np.float32))
+    eye = np.eye(K, dtype=np.float32)
+    out = host(ops.gemv_fp8_bf16_batched(dev(eye[:8], "bfloat16"), from_numpy(W), from_numpy(scale)))
+    for m in range(8):
+        np.testing.assert_array_equal(out[m, m], O.bf16_round(np.array([table[codes[m]]], np.float32))[0])
+    # all codes: y[n] = sum_k x[k] * W[n,k] with x = ones picks the diagonal code
+    y = host(ops.gemv_fp8_bf16(dev(np.ones(K, np.float32), "bfloat16"), from_numpy(W), from_numpy(scale)))
+    np.testing.assert_array_equal(y[: len(codes)], O.bf16_round(table[codes]))
+
+
+@pytest.mark.parametrize("m", [1, 3, 8, 11])
+def test_gemv_fp8(m):
+    rng = np.random.default_rng(7)
+    K, N = 1024, 512
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    codes, sbits = O.quantize_fp8_e4m3_block(w)
+    a = rng.standard_normal((m, K)).astype(np.float32)
+    ref = O.bf16_round(a) @ O.dequantize_fp8_e4m3_block(codes, sbits).T
+    if m == 1:
+        c = host(ops.gemv_fp8_bf16(dev(a[0], "bfloat16"), from_numpy(codes), from_numpy(sbits)))[None]
+    else:
+        c = host(ops.gemv_fp8_bf16_batched(dev(a, "bfloat16"), from_numpy(codes), from_numpy(sbits)))
+    assert rel_err(c, ref) < 1e-2  # vs the fp32 dequantised oracle
+    assert rel_err(c, O.bf16_round(a) @ w.T) < 5e-2  # vs the unquantised weights (BASELINE fp8 bar)
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16", "float32"])
+@pytest.mark.parametrize("mnk", [(128, 256, 1024), (16, 96, 80), (33, 100, 72), (7, 19, 33), (200, 1024, 512), (64, 3072, 1024)])
+def test_gemm_nt_nn(dt, mnk):
+    M, N, K = mnk
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ar, wr = rounded(a, dt).astype(np.float64), rounded(w, dt).astype(np.float64)
+    ref = (ar @ wr.T).astype(np.float32)
+    close(host(ops.matmul_nt(dev(a, dt), dev(w, dt))), ref, dt)
+    close(host(ops.matmul_nt(dev(a, dt), dev(w, dt), dev(bias, dt))), ref + rounded(bias, dt), dt)
+    close(host(ops.matmul(dev(a, dt), dev(np.ascontiguousarray(w.T), dt))), ref, dt)
+    out = pk.empty((M, N), dt)
+    ops.matmul(dev(a, dt), dev(np.ascontiguousarray(w.T), dt), out=out)
+    close(host(out), ref, dt)
+
+
+def test_matmul_golden_fp32():
+    for tag in ("m1", "m16", "m128", "odd"):
+        c = host(ops.matmul(dev(g1[f"matmul_{tag}_a"]), dev(g1[f"matmul_{tag}_b"])))
+        np.testing.assert_allclose(c, g1[f"matmul_{tag}_c"], rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        ops.matmul(dev(np.zeros((2, 3))), dev(np.zeros((4, 5))))
+
+
+@pytest.mark.parametrize("m", [16, 100])
+def test_w8a16_gemm_kn(m):
+    rng = np.random.default_rng(9)
+    K, N = 512, 384
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    codes, sbits = O.quantize_fp8_e4m3_block(w)  # [N,K], scale [N/128,K/128]
+    a = rng.standard_normal((m, K)).astype(np.float32)
+    ref = O.bf16_round(a) @ O.dequantize_fp8_e4m3_block(codes, sbits).T
+    b_kn = from_numpy(np.ascontiguousarray(codes.T))
+    s_kn = from_numpy(np.ascontiguousarray(sbits.T))
+    c = host(ops.w8a16_gemm_sm120(dev(a, "bfloat16"), b_kn, s_kn))
+    assert rel_err(c, ref) < 1e-2
+    # layout-equivalence the reference relies on (linear.py:173-179): GEMV on [N,K] == GEMM on [K,N]
+    c2 = host(ops.gemv_fp8_bf16_batched(dev(a[:8], "bfloat16"), from_numpy(codes), from_numpy(sbits)))
+    assert rel_err(c[:8], c2) < 1e-2
+
+
+# ----------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("tag", ["off", "sq", "dec"])
+def test_sdpa_golden_fp32(tag):
+    o = host(ops.sdpa_causal(dev(g1[f"sdpa_{tag}_q"]), dev(g1[f"sdpa_{tag}_k"]), dev(g1[f"sdpa_{tag}_v"])))
+    np.testing.assert_allclose(o, g1[f"sdpa_{tag}_o"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("cfg", [(4, 4, 9, 9, 128), (4, 2, 3, 11, 64), (16, 8, 128, 128, 128), (8, 2, 70, 200, 128),
+                                 (2, 2, 130, 130, 64), (4, 1, 1, 37, 128)])
+def test_sdpa_flash_prefill(dt, cfg):
+    hq, hkv, ql, kl, d = cfg
+    rng = np.random.default_rng(10)
+    q, k, v = (rng.standard_normal(s).astype(np.float32) for s in ((hq, ql, d), (hkv, kl, d), (hkv, kl, d)))
+    qr, kr, vr = rounded(q, dt), rounded(k, dt), rounded(v, dt)
+    rep = hq // hkv
+    ref = O.sdpa_causal(qr, np.repeat(kr, rep, axis=0), np.repeat(vr, rep, axis=0))
+    o = host(ops.sdpa_causal(dev(q, dt), dev(k, dt), dev(v, dt)))
+    close(o, ref, dt)
+    assert np.abs(o - ref).max() < 5e-2  # reference's FA2-vs-SDPA bar (benchmarks/test_flash_attention.py:169)
+
+
+def test_sdpa_softmax_max_jump():
+    """Force the online-softmax rescale: one key far above the rest late in the sequence."""
+    rng = np.random.default_rng(11)
+    hq, ql, d = 2, 192, 128
+    q, k, v = (rng.standard_normal((hq, ql, d)).astype(np.float32) for _ in range(3))
+    k[:, 150] = q[:, 160] * 3.0  # huge score for queries >= 150 at kv tile 2
+    ref = O.sdpa_causal(O.bf16_round(q), O.bf16_round(k), O.bf16_round(v))
+    o = host(ops.sdpa_causal(dev(q, "bfloat16"), dev(k, "bfloat16"), dev(v, "bfloat16")))
+    close(o, ref, "bfloat16")
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float32"])
+@pytest.mark.parametrize("cfg", [(16, 8, 128, 2112, 2048), (16, 16, 128, 512, 100), (8, 2, 64, 300, 299), (4, 4, 128, 64, 1)])
+def test_sdpa_fixed_cache_decode(dt, cfg):
+    hq, hc, d, max_seq, ctx = cfg
+    rng = np.random.default_rng(12)
+    q = rng.standard_normal((hq, 1, d)).astype(np.float32)
+    kc = rng.standard_normal((hc, max_seq, d)).astype(np.float32)
+    vc = rng.standard_normal((hc, max_seq, d)).astype(np.float32)
+    kc[:, ctx:], vc[:, ctx:] = 1e4, 1e4  # garbage beyond the context must never be read into the result
+    ref = O.sdpa_causal_fixed_cache(rounded(q, dt), rounded(kc, dt), rounded(vc, dt), ctx)
+    out = pk.empty((hq, 1, d), dt)
+    ops.sdpa_causal_fixed_cache(dev(q, dt), dev(kc, dt), dev(vc, dt), out, ctx)
+    close(host(out), ref, dt)
+    assert np.abs(host(out) - ref).max() < 1e-2  # reference's flash-decoding bar (benchmarks/test_flash_decoding.py:76)
+    out2 = pk.empty((hq, 1, d), dt)
+    ops.sdpa_causal_fixed_cache_ptr(dev(q, dt), dev(kc, dt), dev(vc, dt), out2, from_numpy(np.array([ctx], np.int32)), max_seq)
+    np.testing.assert_array_equal(out2.to_numpy(), out.to_numpy())
+
+
+def test_sdpa_fixed_cache_multi_query():
+    rng = np.random.default_rng(13)
+    hq, hc, d, max_seq, ctx, ql = 4, 2, 128, 96, 50, 5
+    q = rng.standard_normal((hq, ql, d)).astype(np.float32)
+    kc, vc = (rng.standard_normal((hc, max_seq, d)).astype(np.float32) for _ in range(2))
+    ref = O.sdpa_causal_fixed_cache(O.bf16_round(q), O.bf16_round(kc), O.bf16_round(vc), ctx)
+    out = pk.empty((hq, ql, d), "bfloat16")
+    ops.sdpa_causal_fixed_cache(dev(q, "bfloat16"), dev(kc, "bfloat16"), dev(vc, "bfloat16"), out, ctx)
+    close(host(out), ref, "bfloat16")
+    with pytest.raises(ValueError):
+        ops.sdpa_causal_fixed_cache(dev(q, "bfloat16"), dev(kc, "bfloat16"), dev(vc, "bfloat16"), out, max_seq + 1)
+
+
+# ----------------------------------------------------------------------------- graph
+def test_graph_capture_replay_reads_device_scalars():
+    """Capture embedding_lookup_ptr + rmsnorm once; replay with a different token id in the device buffer."""
+    rng = np.random.default_rng(14)
+    E = rng.standard_normal((20, 256)).astype(np.float32)
+    Ed, g = dev(E, "bfloat16"), dev(np.ones(256, np.float32), "bfloat16")
+    tok = from_numpy(np.array([3], np.int32))
+    x, y = pk.empty((1, 256), "bfloat16"), pk.empty((1, 256), "bfloat16")
+    graph = pk.CudaGraph()
+    graph.begin_capture()
+    ops.embedding_lookup_ptr(Ed, x, tok)
+    ops.rmsnorm(x, g, 1e-6, out=y)
+    graph.end_capture()
+    assert graph.is_ready() and graph.num_nodes >= 2
+    for t in (3, 11, 19):
+        tok.copy_from_numpy(np.array([t], np.int32))
+        graph.replay()
+        graph.synchronize()
+        close(host(y), O.rmsnorm(O.bf16_round(E[t : t + 1]), np.ones(256, np.float32), 1e-6), "bfloat16")

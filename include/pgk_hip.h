@@ -134,6 +134,10 @@ pgk_status pgk_bias_add_inplace(void* out, const void* bias, int rows, int featu
 pgk_status pgk_activation(const void* x, void* y, size_t n, int act, pgk_dtype dt, pgk_stream s);
 /* ops.cuh:206-212 swiglu / geglu: out = act(gate) * up ; act: 0 silu, 1 gelu */
 pgk_status pgk_glu(const void* gate, const void* up, void* out, size_t n, int act, pgk_dtype dt, pgk_stream s);
+/* Row-packed GLU: gate_up[rows, 2*inter] (gate columns then up columns, the fused gate_up projection of
+ * src/pygpukit/llm/layers/mlp.py:84-86) -> out[rows, inter] = act(gate) * up.  Replaces the reference's
+ * narrow + silu + mul_inplace sequence (models/causal.py:537-549), which is only exact for rows == 1. */
+pgk_status pgk_glu_packed(const void* gate_up, void* out, int rows, int inter, int act, pgk_dtype dt, pgk_stream s);
 /* ops.cuh:426-436 cast_f32_to_bf16 / f32_to_f16 / bf16_to_f32 / f16_to_f32 (RNE) */
 pgk_status pgk_cast(const void* src, pgk_dtype src_dt, void* dst, pgk_dtype dst_dt, size_t n, pgk_stream s);
 
@@ -205,6 +209,11 @@ pgk_status pgk_gemv_fp8_bf16(const void* a, const uint8_t* b_nk, const void* sca
 /* pygpukit_w8a16_gemm_sm120 (native/bindings/gemm/fp8xbf16_bf16.cpp:9-12):
  * C[M,N] = A[M,K] . dequant(B_fp8[K,N], scale[K/128,N/128]) ; note the [K,N] layout. */
 pgk_status pgk_w8a16_gemm_kn(const void* a, const uint8_t* b_kn, const void* scale, void* c, int m, int n, int k,
+                             pgk_stream s);
+/* Same product on the PyTorch-layout weight W_fp8[N,K] with scale[N/128,K/128] (the layout LinearFP8 stores,
+ * src/pygpukit/llm/layers/linear.py:149-160): avoids the transposed fp8 + scale copies the reference
+ * makes for its M > 1 path (linear.py:173-179). */
+pgk_status pgk_w8a16_gemm_nk(const void* a, const uint8_t* w_nk, const void* scale, void* c, int m, int n, int k,
                              pgk_stream s);
 /* gemm_fp8_fp8_blockwise_sm120 (src/pygpukit/ops/matmul/fp8.py:270-343): fp8 x fp8 MFMA GEMM,
  * A_fp8[M,K] (scale_a[M/1? see DESIGN]) . W_fp8[N,K]^T with 128-wide block scales, bf16 out.

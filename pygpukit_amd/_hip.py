@@ -65,7 +65,7 @@ _PROTOS = {
     "pgk_graph_num_nodes": [_V, C.POINTER(_Z)], "pgk_graph_destroy": [_V], "pgk_stream_is_capturing": [_V, C.POINTER(_I)],
     "pgk_binary": [_V, _V, _V, _Z, _I, _I, _V], "pgk_binary_inplace": [_V, _V, _Z, _I, _I, _V],
     "pgk_bias_add_inplace": [_V, _V, _I, _I, _I, _V], "pgk_activation": [_V, _V, _Z, _I, _I, _V],
-    "pgk_glu": [_V, _V, _V, _Z, _I, _I, _V], "pgk_cast": [_V, _I, _V, _I, _Z, _V],
+    "pgk_glu": [_V, _V, _V, _Z, _I, _I, _V], "pgk_glu_packed": [_V, _V, _I, _I, _I, _I, _V], "pgk_cast": [_V, _I, _V, _I, _Z, _V],
     "pgk_rmsnorm": [_V, _V, _V, _I, _I, _F, _I, _V], "pgk_rmsnorm_residual": [_V, _V, _V, _V, _I, _I, _F, _I, _V],
     "pgk_layernorm": [_V, _V, _V, _V, _I, _I, _F, _I, _V],
     "pgk_rope_inplace": [_V, _V, _V, _V, _I, _I, _I, _I, _I, _I, _V],
@@ -78,7 +78,7 @@ _PROTOS = {
     "pgk_argmax": [_V, _I, _I, _I, _V, _V],
     "pgk_gemm_nn": [_V, _V, _V, _I, _I, _I, _I, _V], "pgk_gemm_nt": [_V, _V, _V, _V, _I, _I, _I, _I, _V],
     "pgk_gemv": [_V, _V, _V, _I, _I, _I, _V], "pgk_gemv_fp8_bf16": [_V, _V, _V, _V, _I, _I, _I, _V],
-    "pgk_w8a16_gemm_kn": [_V, _V, _V, _V, _I, _I, _I, _V],
+    "pgk_w8a16_gemm_kn": [_V, _V, _V, _V, _I, _I, _I, _V], "pgk_w8a16_gemm_nk": [_V, _V, _V, _V, _I, _I, _I, _V],
     "pgk_gemm_fp8_nt": [_V, _V, _V, _V, _V, _I, _I, _I, _V], "pgk_quantize_fp8_rows": [_V, _V, _V, _I, _I, _V],
     "pgk_sdpa_causal": [_V, _V, _V, _V, _I, _I, _I, _I, _I, _F, _I64, _I64, _I64, _I64, _I64, _I64, _I, _V],
     "pgk_sdpa_fixed_cache": [_V, _V, _V, _V, _I, _I, _I, _I, _I, _F, _I, _V, _V, _I, _V],

@@ -135,6 +135,35 @@ __global__ void glu_kernel(const T* g, const T* u, T* o, size_t n, int act) {
     for (size_t i = done + tid; i < n; i += stride) o[i] = from_f<T>(act_fn(to_f(g[i]), act) * to_f(u[i]));
 }
 
+// out[r][i] = act(gu[r][i]) * gu[r][inter + i]
+template <class T, bool VECTOR>
+__global__ void glu_packed_kernel(const T* gu, T* o, size_t rows, int inter, int act) {
+    constexpr int N = Vec<T>::N;
+    const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    if (VECTOR) {  // inter % N == 0
+        const int iv = inter / N;
+        for (size_t t = tid; t < rows * iv; t += stride) {
+            const size_t r = t / iv, c = (t % iv) * N;
+            Vec<T> vg, vu;
+            vg.load(gu + r * 2 * inter + c);
+            vu.load(gu + r * 2 * inter + inter + c);
+            float fg[N], fu[N];
+            vg.to_float(fg);
+            vu.to_float(fu);
+#pragma unroll
+            for (int j = 0; j < N; ++j) fg[j] = act_fn(fg[j], act) * fu[j];
+            vg.from_float(fg);
+            vg.store(o + r * inter + c);
+        }
+    } else {
+        for (size_t t = tid; t < rows * inter; t += stride) {
+            const size_t r = t / inter, c = t % inter;
+            o[t] = from_f<T>(act_fn(to_f(gu[r * 2 * inter + c]), act) * to_f(gu[r * 2 * inter + inter + c]));
+        }
+    }
+}
+
 template <class S, class D>
 __global__ void cast_kernel(const S* src, D* dst, size_t n) {
     const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -217,6 +246,23 @@ pgk_status pgk_glu(const void* gate, const void* up, void* out, size_t n, int ac
         const int grid = ew_grid(vec ? n / Vec<T>::N + 1 : n);
         if (vec) glu_kernel<T, true><<<grid, EW_BLOCK, 0, st>>>((const T*)gate, (const T*)up, (T*)out, n, act);
         else glu_kernel<T, false><<<grid, EW_BLOCK, 0, st>>>((const T*)gate, (const T*)up, (T*)out, n, act);
+    });
+    PGK_LAUNCH_CHECK();
+    return PGK_OK;
+}
+
+pgk_status pgk_glu_packed(const void* gate_up, void* out, int rows, int inter, int act, pgk_dtype dt, pgk_stream s) {
+    PGK_REQUIRE(gate_up && out, "pgk_glu_packed: null pointer");
+    PGK_REQUIRE(rows >= 0 && inter > 0, "pgk_glu_packed: bad shape [%d, 2*%d]", rows, inter);
+    PGK_REQUIRE(act == 0 || act == 1, "pgk_glu_packed: bad activation %d", act);
+    if (!rows) return PGK_OK;
+    hipStream_t st = resolve_stream(s);
+    PGK_DISPATCH_FLOAT(dt, "pgk_glu_packed", {
+        const bool vec = aligned16(gate_up) && aligned16(out) && (inter % Vec<T>::N == 0);
+        const size_t n = (size_t)rows * inter;
+        const int grid = ew_grid(vec ? n / Vec<T>::N : n);
+        if (vec) glu_packed_kernel<T, true><<<grid, EW_BLOCK, 0, st>>>((const T*)gate_up, (T*)out, rows, inter, act);
+        else glu_packed_kernel<T, false><<<grid, EW_BLOCK, 0, st>>>((const T*)gate_up, (T*)out, rows, inter, act);
     });
     PGK_LAUNCH_CHECK();
     return PGK_OK;

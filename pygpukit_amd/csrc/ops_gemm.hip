@@ -394,6 +394,16 @@ pgk_status pgk_gemm_nn(const void* a, const void* b, void* c, int m, int n, int 
     return dispatch_mfma<f16, B_NN>((const f16*)a, b, nullptr, nullptr, (f16*)c, m, n, k, st);
 }
 
+pgk_status pgk_w8a16_gemm_nk(const void* a, const uint8_t* w_nk, const void* scale, void* c, int m, int n, int k,
+                             pgk_stream s) {
+    PGK_REQUIRE(a && w_nk && scale && c, "pgk_w8a16_gemm_nk: null pointer");
+    PGK_REQUIRE(m >= 0 && n > 0 && k > 0, "pgk_w8a16_gemm_nk: bad shape M=%d N=%d K=%d", m, n, k);
+    PGK_REQUIRE(k % 128 == 0 && n % 128 == 0, "pgk_w8a16_gemm_nk: K=%d, N=%d must be multiples of the 128x128 scale block", k, n);
+    PGK_REQUIRE(aligned16(a) && aligned16(w_nk), "pgk_w8a16_gemm_nk: operands must be 16-byte aligned");
+    if (!m) return PGK_OK;
+    return dispatch_mfma<bf16, B_NT_FP8>((const bf16*)a, w_nk, (const bf16*)scale, nullptr, (bf16*)c, m, n, k, resolve_stream(s));
+}
+
 pgk_status pgk_w8a16_gemm_kn(const void* a, const uint8_t* b_kn, const void* scale, void* c, int m, int n, int k,
                              pgk_stream s) {
     PGK_REQUIRE(a && b_kn && scale && c, "pgk_w8a16_gemm_kn: null pointer");

@@ -1,0 +1,16 @@
+"""LLM layer of pygpukit_amd: config, layers, CausalTransformerModel, decode strategies, native engine."""
+
+from pygpukit_amd.llm.buffers import DecodeBuffers, PrefillBuffers
+from pygpukit_amd.llm.config import (GPT2_SPEC, LLAMA_SPEC, MODEL_SPECS, QWEN2_SPEC, QWEN3_SPEC, ModelSpec, TransformerConfig,
+                                    detect_model_spec)
+from pygpukit_amd.llm.decode import DecodeBatch, DecodeM1, DecodeM1Graph, DecodeStrategy
+from pygpukit_amd.llm.engine import Engine
+from pygpukit_amd.llm.layers import (MLP, Attention, Linear, LinearBF16, LinearFP8, Norm, TransformerBlock,
+                                    precompute_freqs_cis)
+from pygpukit_amd.llm.models import CausalTransformerModel, GPT2Model, LlamaModel, QwenModel
+from pygpukit_amd.llm.sampling import sample_token
+
+__all__ = ["DecodeBuffers", "PrefillBuffers", "ModelSpec", "TransformerConfig", "GPT2_SPEC", "LLAMA_SPEC", "QWEN2_SPEC",
+           "QWEN3_SPEC", "MODEL_SPECS", "detect_model_spec", "DecodeStrategy", "DecodeM1", "DecodeM1Graph", "DecodeBatch",
+           "Engine", "MLP", "Attention", "Linear", "LinearBF16", "LinearFP8", "Norm", "TransformerBlock",
+           "precompute_freqs_cis", "CausalTransformerModel", "GPT2Model", "LlamaModel", "QwenModel", "sample_token"]

@@ -1,0 +1,153 @@
+"""Python handle on the native decode/prefill engine (pgk_engine_* in include/pgk_hip.h).
+
+One C call enqueues a whole token step (5 fused kernels per layer); `capture()` records it into ONE
+hipGraph whose token id / position live in device memory, so `replay(n)` runs n greedy steps with no
+host round trip.  This is what DecodeM1Graph / DecodeBatch drive; the reference's counterpart is the
+2L+2-graph replay loop of src/pygpukit/llm/decode/m1_graph.py:463-589."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from pygpukit_amd import _hip
+from pygpukit_amd.core.array import GPUArray
+from pygpukit_amd.core.dtypes import bfloat16, float32
+
+
+class Engine:
+    def __init__(self, config: dict, embed: GPUArray, layers: list[dict], final_norm: GPUArray, lm_head: GPUArray | None = None,
+                 *, max_seq_len: int = 512, max_batch: int = 1, weight_format: str = "bf16", use_qk_norm: bool = True):
+        """config: vocab_size, hidden_size, num_layers, num_heads, num_kv_heads, head_dim, intermediate_size,
+        norm_eps, rope_theta.  layers[i]: GPUArrays attn_norm, w_qkv [(Hq+2Hkv)D, H], q_norm, k_norm, w_o,
+        mlp_norm, w_gate_up [2I, H], w_down (+ s_qkv, s_o, s_gate_up, s_down for fp8)."""
+        _hip.require_device()
+        self.config = dict(config)
+        self.max_seq_len, self.max_batch = max_seq_len, max_batch
+        self.weight_format = weight_format
+        self._keep = [embed, final_norm, lm_head, layers]  # keep the weights alive
+        mc = _hip.ModelConfig(config["vocab_size"], config["hidden_size"], config["num_layers"], config["num_heads"],
+                              config["num_kv_heads"], config["head_dim"], config["intermediate_size"], max_seq_len, max_batch,
+                              float(config["norm_eps"]), float(config["rope_theta"]), 1 if weight_format == "fp8" else 0,
+                              1 if use_qk_norm else 0)
+        for a in (embed, final_norm):
+            if a.dtype != bfloat16:
+                raise ValueError("Engine: embedding / norm weights must be bfloat16")
+        arr = (_hip.LayerWeights * len(layers))()
+        for i, lw in enumerate(layers):
+            for name, _ in _hip.LayerWeights._fields_:
+                t = lw.get(name)
+                setattr(arr[i], name, t.data_ptr() if t is not None else None)
+        h = C.c_void_p()
+        _hip.call("pgk_engine_create", C.byref(mc), embed._p, lm_head._p if lm_head is not None else None, final_norm._p,
+                  arr, C.byref(h))
+        self._h = h.value
+        self._captured_batch = 0
+        self.last_prefill_logits: np.ndarray | None = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", 0):
+                _hip.call("pgk_engine_destroy", C.c_void_p(self._h))
+        except Exception:
+            pass
+        self._h = 0
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return C.c_void_p(self._h)
+
+    def bytes(self) -> tuple[int, int]:
+        kv, ws = C.c_size_t(), C.c_size_t()
+        _hip.call("pgk_engine_bytes", self.handle, C.byref(kv), C.byref(ws))
+        return kv.value, ws.value
+
+    # ------------------------------------------------------------------ prefill
+    def prefill(self, tokens, seq: int = 0, start_pos: int = 0, *, want_last_logits: bool = True,
+                all_logits: GPUArray | None = None) -> np.ndarray | None:
+        """Run the prompt through the MFMA path, filling sequence slot `seq`'s KV rows; returns the last
+        row's logits (fp32 [V]) when asked.  all_logits: optional bf16 [n, V] device buffer."""
+        toks = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = np.empty(self.config["vocab_size"], np.float32) if want_last_logits else None
+        _hip.call("pgk_engine_prefill", self.handle, seq, toks.ctypes.data_as(_hip.c_i32_p), len(toks), start_pos,
+                  all_logits._p if all_logits is not None else None,
+                  out.ctypes.data_as(C.POINTER(C.c_float)) if out is not None else None, None)
+        if out is not None:
+            self.last_prefill_logits = out
+        return out
+
+    # ------------------------------------------------------------------ decode
+    def set_state(self, tokens, positions) -> None:
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        p = np.ascontiguousarray(positions, dtype=np.int32)
+        if len(t) != len(p):
+            raise ValueError("set_state: tokens and positions must have the same length")
+        _hip.call("pgk_engine_set_state", self.handle, t.ctypes.data_as(_hip.c_i32_p), p.ctypes.data_as(_hip.c_i32_p), len(t), None)
+
+    def decode_step(self, batch: int = 1) -> None:
+        """Enqueue one eager (un-captured) step."""
+        _hip.call("pgk_engine_decode_step", self.handle, batch, None)
+
+    def capture(self, batch: int = 1) -> None:
+        _hip.call("pgk_engine_capture", self.handle, batch, None)
+        self._captured_batch = batch
+
+    def replay(self, n_steps: int = 1) -> None:
+        _hip.call("pgk_engine_replay", self.handle, n_steps, None)
+
+    def synchronize(self) -> None:
+        _hip.call("pgk_stream_sync", None)
+
+    def reset_log(self) -> None:
+        _hip.call("pgk_engine_reset_log", self.handle, None)
+
+    def read_tokens(self, batch: int, n_steps: int) -> np.ndarray:
+        out = np.empty((n_steps, batch), np.int32)
+        _hip.call("pgk_engine_read_tokens", self.handle, out.ctypes.data_as(_hip.c_i32_p), batch, n_steps, None)
+        return out
+
+    def logits(self, batch: int = 1) -> GPUArray:
+        """fp32 [batch, V] view of the last step's logits (owned by the engine)."""
+        p = C.c_void_p()
+        _hip.call("pgk_engine_logits_ptr", self.handle, C.byref(p))
+        a = GPUArray((batch, self.config["vocab_size"]), float32, p.value, owns_memory=False)
+        a._source_ref = self
+        return a
+
+    def kv_cache(self, layer: int) -> tuple[GPUArray, GPUArray]:
+        """bf16 [max_batch, Hkv, max_seq, D] views of layer `layer`'s K and V caches."""
+        k, v = C.c_void_p(), C.c_void_p()
+        _hip.call("pgk_engine_kv_ptr", self.handle, layer, C.byref(k), C.byref(v))
+        shape = (self.max_batch, self.config["num_kv_heads"], self.max_seq_len, self.config["head_dim"])
+        ka, va = GPUArray(shape, bfloat16, k.value, owns_memory=False), GPUArray(shape, bfloat16, v.value, owns_memory=False)
+        ka._source_ref = va._source_ref = self
+        return ka, va
+
+    def launches_per_step(self) -> int:
+        n = C.c_int()
+        _hip.call("pgk_engine_launches_per_step", self.handle, C.byref(n))
+        return n.value
+
+    # ------------------------------------------------------------------ convenience
+    def generate_greedy(self, prompt, max_new_tokens: int, *, use_graph: bool = True) -> list[int]:
+        """Prompt + max_new_tokens greedy tokens for one sequence (slot 0): prefill, argmax of the last
+        row (lowest index on ties), then max_new_tokens-1 device-resident decode steps."""
+        prompt = [int(t) for t in prompt]
+        logits = self.prefill(prompt, seq=0, start_pos=0)
+        first = int(np.argmax(logits))
+        out = prompt + [first]
+        n = max_new_tokens - 1
+        if n <= 0:
+            return out[: len(prompt) + max_new_tokens]
+        self.set_state([first], [len(prompt)])
+        self.reset_log()
+        if use_graph:
+            if self._captured_batch != 1:
+                self.capture(1)
+            self.replay(n)
+        else:
+            for _ in range(n):
+                self.decode_step(1)
+        self.synchronize()
+        return out + [int(t) for t in self.read_tokens(1, n)[:, 0]]

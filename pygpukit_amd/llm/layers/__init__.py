@@ -1,0 +1,9 @@
+from .attention import Attention
+from .block import TransformerBlock
+from .linear import Linear, LinearBF16, LinearFP8, quantize_linear_fp8
+from .mlp import MLP
+from .norm import Norm
+from .rope import precompute_freqs_cis
+
+__all__ = ["Attention", "TransformerBlock", "Linear", "LinearBF16", "LinearFP8", "MLP", "Norm", "precompute_freqs_cis",
+           "quantize_linear_fp8"]

@@ -1,0 +1,97 @@
+"""Random-init model builders for the BASELINE shapes (Qwen3-0.6B, Llama-3-8B) and for tests: take the
+fp32 (bf16-rounded) weight dict produced by the shared generator (same draws as the CPU oracle uses) and
+put it on the GPU, either as an Engine or as a CausalTransformerModel."""
+
+from __future__ import annotations
+
+import numpy as np
+
+from pygpukit_amd.core.array import GPUArray
+from pygpukit_amd.core.factory import from_numpy
+
+
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def _bf16(x: np.ndarray) -> GPUArray:
+    return from_numpy(f32_to_bf16_bits(x).reshape(x.shape))
+
+
+def engine_layer_arrays(lw: dict, weight_format: str = "bf16") -> dict:
+    """One layer of the oracle's weight dict (q,k,v,o,gate,up,down,*_norm as fp32 ndarrays) -> engine layout."""
+    from pygpukit_amd.llm.layers.linear import quantize_linear_fp8
+
+    out = {"attn_norm": _bf16(lw["attn_norm"]), "mlp_norm": _bf16(lw["mlp_norm"]),
+           "q_norm": _bf16(lw["q_norm"]) if "q_norm" in lw else None, "k_norm": _bf16(lw["k_norm"]) if "k_norm" in lw else None}
+    mats = {"w_qkv": np.concatenate([lw["q"], lw["k"], lw["v"]], axis=0), "w_o": lw["o"],
+            "w_gate_up": np.concatenate([lw["gate"], lw["up"]], axis=0), "w_down": lw["down"]}
+    for name, m in mats.items():
+        if weight_format == "fp8":
+            codes, scale = quantize_linear_fp8(np.ascontiguousarray(m, dtype=np.float32))
+            out[name], out["s" + name[1:]] = codes, scale
+        else:
+            out[name] = _bf16(m)
+    return out
+
+
+def build_engine_from_weights(cfg: dict, weights: dict, *, max_seq_len: int = 512, max_batch: int = 1,
+                              weight_format: str = "bf16"):
+    from pygpukit_amd.llm.engine import Engine
+
+    layers = [engine_layer_arrays(lw, weight_format) for lw in weights["layers"]]
+    return Engine(cfg, _bf16(weights["embed"]), layers, _bf16(weights["final_norm"]), None, max_seq_len=max_seq_len,
+                  max_batch=max_batch, weight_format=weight_format, use_qk_norm="q_norm" in weights["layers"][0])
+
+
+def build_model_from_weights(cfg: dict, weights: dict, *, dtype: str = "bfloat16", max_pos: int = 2048):
+    """CausalTransformerModel (Qwen3-style) on the GPU from the oracle weight dict."""
+    from pygpukit_amd.llm.config import QWEN3_SPEC, TransformerConfig
+    from pygpukit_amd.llm.layers import MLP, Attention, Norm, TransformerBlock
+    from pygpukit_amd.llm.models.causal import CausalTransformerModel
+
+    def W(x):
+        return _bf16(x) if dtype == "bfloat16" else from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+
+    c = TransformerConfig(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"], num_layers=cfg["num_layers"],
+                          num_heads=cfg["num_heads"], num_kv_heads=cfg["num_kv_heads"], intermediate_size=cfg["intermediate_size"],
+                          _head_dim=cfg["head_dim"], norm_type="rmsnorm", activation="silu", use_rope=True,
+                          max_position_embeddings=max_pos, norm_eps=cfg["norm_eps"], rope_theta=cfg["rope_theta"])
+    eps = cfg["norm_eps"]
+    blocks = []
+    for lw in weights["layers"]:
+        attn = Attention(W(lw["q"]), W(lw["k"]), W(lw["v"]), W(lw["o"]), c, q_norm=Norm(W(lw["q_norm"]), None, "rmsnorm", eps),
+                         k_norm=Norm(W(lw["k_norm"]), None, "rmsnorm", eps))
+        mlp = MLP(c, gate_proj=W(lw["gate"]), up_proj=W(lw["up"]), down_proj=W(lw["down"]))
+        blocks.append(TransformerBlock(Norm(W(lw["attn_norm"]), None, "rmsnorm", eps), attn,
+                                       Norm(W(lw["mlp_norm"]), None, "rmsnorm", eps), mlp))
+    return CausalTransformerModel(c, W(weights["embed"]), blocks, Norm(W(weights["final_norm"]), None, "rmsnorm", eps), None, None,
+                                  QWEN3_SPEC)
+
+
+def make_qwen3_weights(cfg: dict, seed: int = 0, std: float = 0.02) -> dict:
+    """Same generator as oracle.cpu_ref.make_qwen3_weights (kept here so bench.py's GPU leg does not import
+    the oracle): N(0, std^2) float32 draws in the order embed, then per layer q,k,v,o,gate,up,down, each
+    rounded to bf16 and widened back to fp32; norm gammas are 1."""
+    rng = np.random.default_rng(seed)
+    H, D, I, V = cfg["hidden_size"], cfg["head_dim"], cfg["intermediate_size"], cfg["vocab_size"]
+    Hq, Hkv = cfg["num_heads"], cfg["num_kv_heads"]
+
+    def W(*s):
+        w = rng.standard_normal(s, dtype=np.float32) * np.float32(std)
+        return (f32_to_bf16_bits(w).astype(np.uint32) << 16).view(np.float32).reshape(s)
+
+    out = {"embed": W(V, H), "layers": []}
+    for _ in range(cfg["num_layers"]):
+        out["layers"].append(dict(q=W(Hq * D, H), k=W(Hkv * D, H), v=W(Hkv * D, H), o=W(H, Hq * D), gate=W(I, H), up=W(I, H),
+                                  down=W(H, I), attn_norm=np.ones(H, np.float32), mlp_norm=np.ones(H, np.float32),
+                                  q_norm=np.ones(D, np.float32), k_norm=np.ones(D, np.float32)))
+    out["final_norm"] = np.ones(H, np.float32)
+    return out
+
+
+QWEN3_0_6B = dict(vocab_size=151936, hidden_size=1024, num_layers=28, num_heads=16, num_kv_heads=8, head_dim=128,
+                  intermediate_size=3072, rope_theta=1e6, norm_eps=1e-6)
+LLAMA3_8B = dict(vocab_size=128256, hidden_size=4096, num_layers=32, num_heads=32, num_kv_heads=8, head_dim=128,
+                 intermediate_size=14336, rope_theta=5e5, norm_eps=1e-5)

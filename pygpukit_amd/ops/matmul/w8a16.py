@@ -29,5 +29,20 @@ def w8a16_gemm_sm120(a: GPUArray, b_fp8: GPUArray, b_scale: GPUArray, *, out: GP
 w8a16_gemm = w8a16_gemm_sm120
 
 
+def w8a16_gemm_nk(a: GPUArray, w_fp8: GPUArray, w_scale: GPUArray, *, out: GPUArray | None = None) -> GPUArray:
+    """C[M,N] = A[M,K] @ dequant(W_fp8[N,K], scale[N/128,K/128])^T on the stored layout (no transposed copies)."""
+    if a.ndim != 2 or w_fp8.ndim != 2 or a.shape[1] != w_fp8.shape[1]:
+        raise ValueError(f"w8a16_gemm_nk dimension mismatch: {a.shape} @ {w_fp8.shape}^T")
+    if a.dtype != bfloat16 or w_scale.dtype != bfloat16 or w_fp8.dtype != uint8:
+        raise ValueError("w8a16_gemm_nk requires bf16 activations/scales and uint8 weights")
+    M, K = a.shape
+    N = w_fp8.shape[0]
+    if K % 128 or N % 128 or w_scale.shape != (N // 128, K // 128):
+        raise ValueError(f"w8a16_gemm_nk: scale must be [N/128, K/128], got {w_scale.shape}")
+    c = check_out(out, (M, N), bfloat16, "w8a16_gemm_nk")
+    call("pgk_w8a16_gemm_nk", a._p, w_fp8._p, w_scale._p, c._p, M, N, K, None)
+    return c
+
+
 def gemm_w8a16_init_lut() -> None:
     """The reference uploads a 256-entry LUT to constant memory; gfx950 converts e4m3 in hardware."""

@@ -35,3 +35,13 @@ def swiglu(gate_proj: GPUArray, up_proj: GPUArray, *, out: GPUArray | None = Non
 def geglu(gate_proj: GPUArray, up_proj: GPUArray, *, out: GPUArray | None = None) -> GPUArray:
     """gelu(gate) * up."""
     return _glu(gate_proj, up_proj, 1, "geglu", out)
+
+
+def glu_packed(gate_up: GPUArray, inter: int, *, activation: str = "silu", out: GPUArray | None = None) -> GPUArray:
+    """gate_up [rows, 2*inter] (fused gate_up projection) -> act(gate) * up as [rows, inter]."""
+    validate_float(gate_up, "glu_packed")
+    if gate_up.ndim != 2 or gate_up.shape[1] != 2 * inter:
+        raise ValueError(f"glu_packed: expected [rows, {2 * inter}], got {gate_up.shape}")
+    o = check_out(out, (gate_up.shape[0], inter), gate_up.dtype, "glu_packed")
+    call("pgk_glu_packed", gate_up._p, o._p, gate_up.shape[0], inter, 0 if activation == "silu" else 1, gate_up.dtype.code, None)
+    return o

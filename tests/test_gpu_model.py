@@ -1,0 +1,218 @@
+"""GPU parity tests at model level: CausalTransformerModel (op surface) and the native engine
+(fused decode kernels + whole-step hipGraph) vs the CPU oracle / golden vectors.
+Bars (BASELINE.json north_star): greedy tokens bit-identical; logits rel L2 err <= 1e-2 (bf16), <= 5e-2 (fp8)."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as O
+from tests.conftest import load_golden, rel_err
+from tests.golden_cfg import TINY
+
+pytestmark = pytest.mark.gpu
+
+pk = pytest.importorskip("pygpukit_amd")
+from pygpukit_amd import llm  # noqa: E402
+from pygpukit_amd.core import bfloat16, from_numpy  # noqa: E402
+from pygpukit_amd.llm import synthetic as S  # noqa: E402
+
+g3 = load_golden("g3_tiny_qwen3.npz")
+PROMPT = [int(t) for t in g3["prompt"]]
+
+
+def f32(a):
+    h = a.to_numpy()
+    return O.bf16_bits_to_f32(h) if a.dtype == bfloat16 else h.astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def tiny_weights():
+    return O.make_qwen3_weights(TINY, seed=int(g3["seed"]), bf16=True)
+
+
+def margin(logits: np.ndarray) -> float:
+    s = np.sort(logits)
+    return float(s[-1] - s[-2])
+
+
+def test_fixture_margins_are_safe():
+    """Token-level parity is only meaningful when the oracle's top-1/top-2 gap exceeds bf16 noise."""
+    for row in g3["step_logits"]:
+        assert margin(row) > 0.02 * np.abs(row).max()
+
+
+@pytest.mark.parametrize("dtype,tol", [("float32", 2e-4), ("bfloat16", 1e-2)])
+def test_model_forward_and_generate_vs_golden(tiny_weights, dtype, tol):
+    model = S.build_model_from_weights(TINY, tiny_weights, dtype=dtype, max_pos=128)
+    hidden, kv = model(PROMPT, use_cache=True)
+    assert hidden.shape == (len(PROMPT), TINY["hidden_size"]) and len(kv) == TINY["num_layers"]
+    assert kv[0][0].shape == (len(PROMPT), TINY["num_kv_heads"], TINY["head_dim"])
+    assert rel_err(f32(hidden), g3["prefill_hidden"]) < tol
+    assert rel_err(f32(model.get_logits(hidden)), g3["prefill_logits"]) < tol
+    ids = model.generate(PROMPT, max_new_tokens=10, temperature=0.0, top_k=0, top_p=1.0)
+    np.testing.assert_array_equal(ids, g3["tokens"])
+    ids_gpu = model.generate(PROMPT, max_new_tokens=10, temperature=0.0, top_k=0, top_p=1.0, gpu_sampling=True)
+    np.testing.assert_array_equal(ids_gpu, g3["tokens"])
+    assert list(model.generate_stream(PROMPT, max_new_tokens=4, temperature=0.0, top_k=0, top_p=1.0)) == list(g3["tokens"][12:16])
+    assert llm.QwenModel is llm.CausalTransformerModel and model.forward(PROMPT)[0].shape == hidden.shape
+
+
+def test_full_width_layer_vs_golden():
+    g5 = load_golden("g5_qwen3_layer.npz")
+    cfg = dict(O.QWEN3_0_6B, num_layers=1, vocab_size=64)
+    w = O.make_qwen3_weights(cfg, seed=int(g5["seed"]), bf16=True)
+    for dtype, tol in (("float32", 2e-4), ("bfloat16", 1e-2)):
+        block = S.build_model_from_weights(cfg, w, dtype=dtype, max_pos=64).blocks[0]
+        x = from_numpy(g5["x"]) if dtype == "float32" else from_numpy(O.f32_to_bf16_bits(g5["x"]))
+        y, kv = block(x, [0, 1, 2, 3, 4, 5], None, True)
+        assert rel_err(f32(y), g5["y"]) < tol
+        x1 = from_numpy(g5["x1"]) if dtype == "float32" else from_numpy(O.f32_to_bf16_bits(g5["x1"]))
+        y1, kv1 = block(x1, [6], kv, True)
+        assert rel_err(f32(y1), g5["y1"]) < tol
+        assert rel_err(f32(kv1[0]), g5["k"]) < tol and rel_err(f32(kv1[1]), g5["v"]) < tol
+
+
+def test_engine_greedy_tokens_and_logits_vs_golden(tiny_weights):
+    eng = S.build_engine_from_weights(TINY, tiny_weights, max_seq_len=128, max_batch=1)
+    toks = eng.generate_greedy(PROMPT, max_new_tokens=10)
+    np.testing.assert_array_equal(toks, g3["tokens"])
+    assert rel_err(eng.last_prefill_logits, g3["step_logits"][0]) < 1e-2
+    # eager (un-captured) launches give the same tokens as graph replay
+    np.testing.assert_array_equal(eng.generate_greedy(PROMPT, max_new_tokens=10, use_graph=False), g3["tokens"])
+    # per-step logits: step t decodes token g3.tokens[12+t-1] at position 12+t-1
+    eng.prefill(PROMPT)
+    for t in range(1, 10):
+        tok, pos = int(g3["tokens"][len(PROMPT) + t - 1]), len(PROMPT) + t - 1
+        eng.set_state([tok], [pos])
+        eng.replay(1)
+        lg = eng.logits(1).to_numpy()[0]
+        assert rel_err(lg, g3["step_logits"][t]) < 1e-2
+        assert int(np.argmax(lg)) == int(g3["tokens"][len(PROMPT) + t])
+    assert eng.launches_per_step() == 5 * TINY["num_layers"] + 4
+
+
+def test_engine_kv_cache_matches_oracle(tiny_weights):
+    ref = O.build_qwen3_ref(TINY, tiny_weights, max_pos=128)
+    _, kv = ref(PROMPT, use_cache=True)
+    eng = S.build_engine_from_weights(TINY, tiny_weights, max_seq_len=128, max_batch=1)
+    eng.prefill(PROMPT)
+    for layer in range(TINY["num_layers"]):
+        k, v = eng.kv_cache(layer)
+        kh = O.bf16_bits_to_f32(k.to_numpy())[0, :, : len(PROMPT)]  # [Hkv, S, D]
+        vh = O.bf16_bits_to_f32(v.to_numpy())[0, :, : len(PROMPT)]
+        assert rel_err(kh, kv[layer][0].transpose(1, 0, 2)) < 1e-2
+        assert rel_err(vh, kv[layer][1].transpose(1, 0, 2)) < 1e-2
+
+
+def test_engine_decode_equals_prefill_row(tiny_weights):
+    """Size-independent property: decoding token t against the cache == row t of a (t+1)-long prefill."""
+    eng = S.build_engine_from_weights(TINY, tiny_weights, max_seq_len=128, max_batch=1)
+    ids = [5, 9, 300, 77, 1000, 12, 800, 3]
+    full = eng.prefill(ids)
+    eng.prefill(ids[:-1])
+    eng.set_state([ids[-1]], [len(ids) - 1])
+    eng.decode_step(1)
+    assert rel_err(eng.logits(1).to_numpy()[0], full) < 5e-3
+
+
+def test_engine_batch_of_independent_sequences(tiny_weights):
+    """BASELINE config 4 semantics at small scale: B sequences, own prompts/lengths, one fused step each."""
+    ref = O.build_qwen3_ref(TINY, tiny_weights, max_pos=128)
+    rng = np.random.default_rng(21)
+    B = 5
+    prompts = [[int(t) for t in rng.integers(0, TINY["vocab_size"], n)] for n in (3, 12, 7, 1, 20)]
+    want = [ref.generate(p, max_new_tokens=6, temperature=0.0, top_k=0, top_p=1.0) for p in prompts]
+    model = S.build_model_from_weights(TINY, tiny_weights, dtype="bfloat16", max_pos=128)
+    strat = llm.DecodeBatch(batch_size=B)
+    strat.bind(model)
+    strat.init_graph(max_seq_len=128)
+    first = strat.prefill(prompts)
+    toks = strat.run_greedy(first, [len(p) for p in prompts], 5)
+    for b in range(B):
+        got = prompts[b] + [int(first[b])] + [int(t) for t in toks[:, b]]
+        assert got == want[b], f"sequence {b}"
+
+
+def test_decode_strategies_api(tiny_weights):
+    model = S.build_model_from_weights(TINY, tiny_weights, dtype="bfloat16", max_pos=128)
+    model.init_fixed_cache(128, "bfloat16")
+    assert model.blocks[0].attn._k_cache.shape == (TINY["num_kv_heads"], 128, TINY["head_dim"])
+    logits = model.prefill_fixed_cache(PROMPT)
+    assert rel_err(f32(logits), g3["prefill_logits"]) < 1e-2
+    first = int(np.argmax(f32(logits)[-1]))
+    assert first == int(g3["tokens"][len(PROMPT)])
+    # eager strategy
+    m1 = llm.DecodeM1()
+    m1.bind(model)
+    bufs = llm.DecodeBuffers.allocate(model.config, dtype="bfloat16", use_qk_norm=True, vocab_size=TINY["vocab_size"])
+    lg = f32(m1.step(first, len(PROMPT), len(PROMPT) + 1, bufs))[0]
+    assert rel_err(lg, g3["step_logits"][1]) < 1e-2
+    # graph strategy, fed from the model's fixed caches
+    mg = llm.DecodeM1Graph()
+    mg.bind(model)
+    with pytest.raises(NotImplementedError):
+        mg.step(first, 0, 1, bufs)
+    mg.init_graph(max_seq_len=128)
+    assert mg.has_graph()
+    mg.load_kv_from_model(len(PROMPT))
+    lg2 = mg.step_graph(first, len(PROMPT), len(PROMPT) + 1).to_numpy()[0]
+    assert rel_err(lg2, g3["step_logits"][1]) < 1e-2
+    with pytest.raises(ValueError):
+        mg.step_graph(first, 5, 9)
+    rest = mg.run_greedy(first, len(PROMPT), 9)
+    assert [first] + rest[:-1] == [int(t) for t in g3["tokens"][len(PROMPT):len(PROMPT) + 9]]
+    # verify-style batch of consecutive tokens of one sequence
+    db = llm.DecodeBatch(batch_size=4)
+    db.bind(model)
+    model.prefill_fixed_cache(PROMPT)
+    nxt = [int(t) for t in g3["tokens"][len(PROMPT):len(PROMPT) + 3]]
+    lgb = f32(db.step_batch(nxt, len(PROMPT), len(PROMPT) + 3))
+    for i in range(3):
+        assert rel_err(lgb[i], g3["step_logits"][i + 1]) < 1e-2
+
+
+def test_engine_fp8_weights(tiny_weights):
+    """w8a16 path (config 3 semantics): fp8-e4m3 linears + bf16 block scales, bf16 embedding / lm_head."""
+    wq = {"embed": tiny_weights["embed"], "final_norm": tiny_weights["final_norm"], "layers": []}
+    for lw in tiny_weights["layers"]:
+        d = dict(lw)
+        # quantise the FUSED matrices exactly as the engine builder does, then split back for the oracle
+        for names in (("q", "k", "v"), ("o",), ("gate", "up"), ("down",)):
+            fused = np.concatenate([lw[n] for n in names], axis=0)
+            codes, sbits = O.quantize_fp8_e4m3_block(fused)
+            deq = O.dequantize_fp8_e4m3_block(codes, sbits)
+            r = 0
+            for n in names:
+                d[n] = deq[r:r + lw[n].shape[0]]
+                r += lw[n].shape[0]
+        wq["layers"].append(d)
+    ref = O.build_qwen3_ref(TINY, wq, max_pos=128)
+    want, want_logits = ref.generate(PROMPT, max_new_tokens=6, temperature=0.0, top_k=0, top_p=1.0, return_logits=True)
+    eng = S.build_engine_from_weights(TINY, tiny_weights, max_seq_len=128, max_batch=1, weight_format="fp8")
+    got = eng.generate_greedy(PROMPT, max_new_tokens=6)
+    assert rel_err(eng.last_prefill_logits, want_logits[0]) < 1e-2  # vs the dequantised-weight oracle
+    # Against the UNQUANTISED bf16 model the gap is the e4m3 weight-quantisation error itself (3 mantissa
+    # bits; the reference quotes ~12 % for its W8A16 GEMV, README.md:455-457): the GPU must add nothing to
+    # what the oracle shows for the same codes.
+    q_err_oracle = rel_err(want_logits[0], g3["step_logits"][0])
+    q_err_gpu = rel_err(eng.last_prefill_logits, g3["step_logits"][0])
+    assert q_err_gpu < 1.1 * q_err_oracle + 1e-3, (q_err_gpu, q_err_oracle)
+    assert got == want
+
+
+def test_qwen3_0_6b_full_size_engine_vs_oracle():
+    """BASELINE config 2 at full size: random-init Qwen3-0.6B, prefill 128 + 8 greedy tokens."""
+    cfg = O.QWEN3_0_6B
+    w = O.make_qwen3_weights(cfg, seed=0, bf16=True)
+    prompt = [int(t) for t in np.random.default_rng(0).integers(0, cfg["vocab_size"], 128)]
+    ref = O.build_qwen3_ref(cfg, w, max_pos=256)
+    want, want_logits = ref.generate(prompt, max_new_tokens=8, temperature=0.0, top_k=0, top_p=1.0, return_logits=True)
+    eng = S.build_engine_from_weights(cfg, w, max_seq_len=256, max_batch=1)
+    got = eng.generate_greedy(prompt, max_new_tokens=8)
+    err = rel_err(eng.last_prefill_logits, want_logits[0])
+    assert err < 1e-2, err
+    assert got == want
+    # last decode step's logits against the oracle's
+    assert rel_err(eng.logits(1).to_numpy()[0], want_logits[-1]) < 1e-2

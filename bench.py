@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BASELINE.json metric "decode tokens/sec/GPU + prefill TFLOPS, Qwen3-0.6B bf16".
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+Workload at N=1 = BASELINE config 2: random-init Qwen3-0.6B-shape bf16 weights, 128-token prompt prefilled
+through the MFMA path, then K single-token greedy decode steps, each ONE replay of the whole-step hipGraph
+(embedding -> 28 layers incl. KV write + attention -> lm_head -> argmax, token/position in device memory).
+A "step" = one decode token for every sequence resident on the GPU (--batch-per-gpu, default 1).
+For N > 1 every rank holds a replica (weights broadcast from rank 0 over RCCL) and its own shard of the
+independent sequences ("weak" scaling: per-GPU work fixed); the only in-loop collective is the all-gather
+of the 4-byte sampled tokens.  `value` = sequences x K / max-over-ranks wall time, inputs resident in HBM.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (the lm_head weight-streaming GEMV, 26 % of the step's bytes):
+                algorithmic bytes / hipEvent-measured launch duration vs 8 TB/s HBM.
+  step_roofline whole decode step: algorithmic bytes per token / measured step time.
+  prefill       ms, TFLOP/s and fraction of the 2.5 PFLOP/s dense bf16 MFMA peak for the 128-token prompt.
+  cpu_baseline  the NumPy oracle (reference-semantics CPU path) timed on this box's host cores, rank 0, N=1.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def algorithmic_bytes_per_token(cfg: dict, ctx: int, weight_format: str) -> dict:
+    """weights read once per step + un-expanded bf16 KV rows + KV write + logits."""
+    H, I, V, L = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"], cfg["num_layers"]
+    D, Hq, Hkv = cfg["head_dim"], cfg["num_heads"], cfg["num_kv_heads"]
+    lin = L * ((Hq + 2 * Hkv) * D * H + H * Hq * D + 2 * I * H + H * I)
+    wbytes = lin * (1 if weight_format == "fp8" else 2)
+    scales = (lin // (128 * 128)) * 2 if weight_format == "fp8" else 0
+    norms = L * (2 * H + 2 * D) * 2 + H * 2
+    lm = V * H * 2
+    kv_row = L * 2 * Hkv * D * 2
+    return {"weights": wbytes + scales + norms, "lm_head": lm, "kv_read": kv_row * ctx, "kv_write": kv_row,
+            "logits": V * 4, "total": wbytes + scales + norms + lm + kv_row * ctx + kv_row + V * 4}
+
+
+def prefill_flops(cfg: dict, S: int, all_rows: bool) -> float:
+    H, I, V, L = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"], cfg["num_layers"]
+    D, Hq, Hkv = cfg["head_dim"], cfg["num_heads"], cfg["num_kv_heads"]
+    per_tok = L * ((Hq + 2 * Hkv) * D * H + H * Hq * D + 3 * I * H)
+    gemm = 2.0 * S * per_tok + 2.0 * (S if all_rows else 1) * V * H
+    attn = 4.0 * S * S * D * Hq * L / 2
+    return gemm + attn
+
+
+def cpu_baseline(cfg, weights, prompt, n_decode: int) -> dict:
+    """Reference-semantics NumPy path (oracle/cpu_ref.py == the reference's CPUSimulationBackend numerics,
+    pinned by tests/golden) on this box's host cores: prefill the prompt, then time n_decode cached steps."""
+    from oracle import cpu_ref as O
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    ref = O.build_qwen3_ref(cfg, weights, max_pos=len(prompt) + n_decode + 8)
+    t0 = time.perf_counter()
+    hidden, past = ref(prompt, use_cache=True)
+    nxt = int(np.argmax(ref.get_logits(hidden[-1:])[0]))
+    t_prefill = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(n_decode):
+        hidden, past = ref([nxt], past_key_values=past, use_cache=True)
+        nxt = int(np.argmax(ref.get_logits(hidden)[0]))
+    dt = time.perf_counter() - t0
+    return {"value": n_decode / dt, "unit": "tokens/s", "cores": int(threads), "kind": "port",
+            "sample": f"NumPy oracle, fp32 on the same bf16-rounded weights: {len(prompt)}-token prefill "
+                      f"({t_prefill:.1f} s) then {n_decode} cached decode steps ({dt:.1f} s)",
+            "prefill_s": t_prefill}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch-per-gpu", type=int, default=1)
+    ap.add_argument("--prompt-len", type=int, default=128)
+    ap.add_argument("--weight-format", choices=["bf16", "fp8"], default="bf16")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-decode-tokens", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (result is then INVALID)")
+    args = ap.parse_args()
+
+    from pygpukit_amd import _hip
+    from pygpukit_amd.llm import synthetic as S
+    from pygpukit_amd.parallel import ControlPlane, RcclComm
+
+    cp = ControlPlane()
+    if cp.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={cp.world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    _hip.call("pgk_device_set", cp.local_rank)
+    comm = RcclComm(cp) if cp.world > 1 else None
+
+    cfg = dict(S.QWEN3_0_6B)
+    if args.layers:
+        cfg["num_layers"] = args.layers
+    B, K, W, P = args.batch_per_gpu, args.steps, args.warmup, args.prompt_len
+    max_seq = P + W + K + 8
+    t_setup = time.perf_counter()
+
+    # ---- weights: rank 0 draws them, every other rank receives them over RCCL (xGMI broadcast) ----
+    weights = S.make_qwen3_weights(cfg, seed=args.seed) if cp.rank == 0 or cp.world == 1 else None
+    bcast_s = None
+    if cp.world == 1:
+        eng = S.build_engine_from_weights(cfg, weights, max_seq_len=max_seq, max_batch=B, weight_format=args.weight_format)
+    else:
+        from pygpukit_amd.core.array import GPUArray
+        from pygpukit_amd.core.dtypes import bfloat16, uint8
+        from pygpukit_amd.llm.engine import Engine
+
+        H, I, V, D = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"], cfg["head_dim"]
+        nq = (cfg["num_heads"] + 2 * cfg["num_kv_heads"]) * D
+        fp8 = args.weight_format == "fp8"
+        wdt = uint8 if fp8 else bfloat16
+        shapes = {"attn_norm": ((H,), bfloat16), "mlp_norm": ((H,), bfloat16), "q_norm": ((D,), bfloat16), "k_norm": ((D,), bfloat16),
+                  "w_qkv": ((nq, H), wdt), "w_o": ((H, cfg["num_heads"] * D), wdt), "w_gate_up": ((2 * I, H), wdt), "w_down": ((H, I), wdt)}
+        if fp8:
+            shapes.update({"s_qkv": ((nq // 128, H // 128), bfloat16), "s_o": ((H // 128, cfg["num_heads"] * D // 128), bfloat16),
+                           "s_gate_up": ((2 * I // 128, H // 128), bfloat16), "s_down": ((H // 128, I // 128), bfloat16)})
+        if cp.rank == 0:
+            embed = S._bf16(weights["embed"])
+            fnorm = S._bf16(weights["final_norm"])
+            layers = [S.engine_layer_arrays(lw, args.weight_format) for lw in weights["layers"]]
+        else:
+            embed, fnorm = GPUArray((V, H), bfloat16), GPUArray((H,), bfloat16)
+            layers = [{k: GPUArray(s, dt) for k, (s, dt) in shapes.items()} for _ in range(cfg["num_layers"])]
+        _hip.call("pgk_device_sync")
+        cp.barrier()
+        t0 = time.perf_counter()
+        nbytes = 0
+        for arr in [embed, fnorm] + [lw[k] for lw in layers for k in shapes]:
+            comm.broadcast(arr, 0)
+            nbytes += arr.nbytes
+        _hip.call("pgk_device_sync")
+        bcast_s = time.perf_counter() - t0
+        eng = Engine(cfg, embed, layers, fnorm, None, max_seq_len=max_seq, max_batch=B, weight_format=args.weight_format)
+
+    # ---- prompts: one independent sequence per (rank, slot) ----
+    rng = np.random.default_rng(1000 + args.seed)
+    all_prompts = rng.integers(0, cfg["vocab_size"], (cp.world * B, P))
+    mine = all_prompts[cp.rank * B:(cp.rank + 1) * B]
+
+    # ---- prefill (MFMA path), timed on sequence slot 0 ----
+    start_ev, stop_ev = _hip.C.c_void_p(), _hip.C.c_void_p()
+    _hip.call("pgk_event_create", _hip.C.byref(start_ev))
+    _hip.call("pgk_event_create", _hip.C.byref(stop_ev))
+    first = np.zeros(B, np.int32)
+    for b in range(B):
+        first[b] = int(np.argmax(eng.prefill([int(t) for t in mine[b]], seq=b)))
+    pf_ms = []
+    for _ in range(5):
+        _hip.call("pgk_event_record", start_ev, None)
+        eng.prefill([int(t) for t in mine[0]], seq=0, want_last_logits=False)
+        _hip.call("pgk_event_record", stop_ev, None)
+        _hip.call("pgk_event_sync", stop_ev)
+        ms = _hip.C.c_float()
+        _hip.call("pgk_event_elapsed_ms", start_ev, stop_ev, _hip.C.byref(ms))
+        pf_ms.append(ms.value)
+    pf_med = float(np.median(pf_ms))
+    pf_flops = prefill_flops(cfg, P, all_rows=False)
+
+    # ---- decode: whole-step hipGraph, state in device memory ----
+    eng.set_state(first, [P] * B)
+    eng.capture(B)
+    tok_dev, _ = eng.state_arrays(B)
+    gathered = None
+    if comm is not None:
+        from pygpukit_amd.core.array import GPUArray
+        from pygpukit_amd.core.dtypes import int32
+
+        gathered = GPUArray((cp.world * B,), int32)
+
+    def run(n):
+        for _ in range(n):
+            eng.replay(1)
+            if comm is not None:
+                comm.all_gather(tok_dev, gathered)  # 4*B bytes per rank, on the same stream, no host sync
+
+    run(W)
+    _hip.call("pgk_device_sync")
+    cp.barrier()
+    _hip.call("pgk_device_sync")
+    t0 = time.perf_counter()
+    _hip.call("pgk_event_record", start_ev, None)
+    run(K)
+    _hip.call("pgk_event_record", stop_ev, None)
+    _hip.call("pgk_device_sync")
+    cp.barrier()
+    wall = time.perf_counter() - t0
+    ms = _hip.C.c_float()
+    _hip.call("pgk_event_elapsed_ms", start_ev, stop_ev, _hip.C.byref(ms))
+    wall_max = cp.max_over_ranks(wall)
+    dev_ms_max = cp.max_over_ranks(ms.value)
+    tokens = eng.read_tokens(B, min(W + K, 4096))
+
+    # ---- per-kernel timing (eager, event after every kernel) for the roofline objects ----
+    prof = eng.profile_step(B, 8)
+    ctx_mid = P + W + K // 2
+    ab = algorithmic_bytes_per_token(cfg, ctx_mid, args.weight_format)
+    lm_us = prof["lmhead"][0]
+    lm_bytes = ab["lm_head"] + cfg["hidden_size"] * 4 * B + cfg["vocab_size"] * 4 * B
+    roofline = {"kernel": "fused_gemv_kernel<bf16, PRO_NORM, EPI_LOGITS> (lm_head + argmax partials)", "bound": "hbm",
+                "achieved": lm_bytes / lm_us / 1e3 if lm_us else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (lm_bytes / lm_us / 1e3 / HBM_PEAK_GBS) if lm_us else None, "traffic": None,
+                "bytes_per_launch": lm_bytes, "us_per_launch": lm_us, "timing": "hipEvent pair around each eager launch, 8 steps"}
+    step_ms = dev_ms_max / K
+    step_bytes = ab["weights"] + ab["lm_head"] + B * (ab["kv_read"] + ab["kv_write"] + ab["logits"])
+    step_roofline = {"bound": "hbm", "achieved": step_bytes / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_step": step_bytes,
+                     "launches_per_step": eng.launches_per_step(), "ctx_mid": ctx_mid,
+                     "kernel_us": {k: round(v[0], 2) for k, v in prof.items()},
+                     "kernel_launches_per_step": {k: v[1] for k, v in prof.items()}}
+
+    result = {
+        "metric": "decode tokens/sec/GPU + prefill TFLOPS (% MFMA peak), Qwen3-0.6B bf16",
+        "value": cp.world * B * K / wall_max, "unit": "tokens/s", "n_gpus": cp.world, "steps": K, "warmup": W,
+        "ms_per_step": wall_max * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if args.weight_format == "bf16" else "fp8-e4m3 weights x bf16", "data": "synthetic",
+        "config": {"workload": f"Qwen3-0.6B-shape random-init {args.weight_format}, prefill {P} + {K}-token greedy decode, "
+                               f"whole-step hipGraph (BASELINE config 2{'' if B == 1 and cp.world == 1 else ' shape, DP replicas'})",
+                   "batch_per_gpu": B, "global_batch": cp.world * B, "prompt_len": P, "parallelism": f"dp{cp.world}",
+                   "layers": cfg["num_layers"]},
+        "tokens_per_s_per_gpu": B * K / wall_max, "device_ms_per_step": step_ms,
+        "roofline": roofline, "step_roofline": step_roofline,
+        "prefill": {"ms": pf_med, "tflops": pf_flops / (pf_med * 1e-3) / 1e12, "flops": pf_flops, "logits": "last row only",
+                    "frac_mfma_peak": pf_flops / (pf_med * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "runs_ms": [round(x, 3) for x in pf_ms]},
+        "first_tokens": [int(t) for t in tokens[: min(8, len(tokens)), 0]],
+        "setup_s": time.perf_counter() - t_setup,
+    }
+    if bcast_s is not None:
+        result["weight_broadcast"] = {"seconds": bcast_s, "GB": nbytes / 1e9, "GBps": nbytes / 1e9 / bcast_s}
+    if args.layers:
+        result["INVALID"] = "layer count overridden"
+    if cp.rank == 0 and cp.world == 1 and not args.no_cpu_baseline:
+        del eng
+        result["cpu_baseline"] = cpu_baseline(cfg, weights, [int(t) for t in mine[0]], args.cpu_decode_tokens)
+    elif cp.rank == 0:
+        result["cpu_baseline"] = None
+    if cp.rank == 0:
+        print(json.dumps(result))
+    cp.barrier()
+    if comm is not None:
+        comm.destroy()
+    cp.shutdown()
+
+
+if __name__ == "__main__":
+    main()

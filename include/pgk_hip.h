@@ -285,6 +285,10 @@ pgk_status pgk_engine_set_state(pgk_engine e, const int32_t* h_tokens, const int
  * state.token = argmax, state.position += 1, and the token is appended to the engine's device
  * token log.  No host interaction: any number of steps can be queued back to back. */
 pgk_status pgk_engine_decode_step(pgk_engine e, int batch, pgk_stream s);
+/* Eager steps with a hipEvent after every kernel: per-kernel-class time sums (ms) and launch counts for the
+ * 8 classes embed, norm_qkv, attn, oproj, gateup, down, lmhead, argmax (in that order).  Advances the
+ * decode state like n_iters ordinary steps. */
+pgk_status pgk_engine_profile_step(pgk_engine e, int batch, int n_iters, float* h_ms_sum, int* h_count, pgk_stream s);
 /* Capture decode_step(batch) into a hipGraph owned by the engine / replay it. */
 pgk_status pgk_engine_capture(pgk_engine e, int batch, pgk_stream s);
 pgk_status pgk_engine_replay(pgk_engine e, int n_steps, pgk_stream s);
@@ -292,8 +296,15 @@ pgk_status pgk_engine_replay(pgk_engine e, int n_steps, pgk_stream s);
 pgk_status pgk_engine_logits_ptr(pgk_engine e, void** logits_f32);
 pgk_status pgk_engine_read_tokens(pgk_engine e, int32_t* h_out, int batch, int n_steps, pgk_stream s);
 pgk_status pgk_engine_reset_log(pgk_engine e, pgk_stream s);
+/* Diagnostic: per logged step, {s_memtime (shader clock ticks), s_memrealtime (100 MHz ticks)} stamped by the
+ * step's last kernel: the in-kernel shader clock between two steps is d(memtime)/d(memrealtime) x 100 MHz
+ * (MI355X_MICROARCH.md, DVFS give-back item 6).  h_out: uint64[2 * n_steps]. */
+pgk_status pgk_engine_read_clock(pgk_engine e, uint64_t* h_out, int n_steps, pgk_stream s);
 /* KV cache access for parity tests: pointers to layer `l`'s K and V caches [max_batch,Hkv,max_seq,D] bf16 */
 pgk_status pgk_engine_kv_ptr(pgk_engine e, int layer, void** k, void** v);
+/* device int32[max_batch] arrays holding each sequence's current token and position (the step's inputs and,
+ * after it, its sampled tokens): what the data-parallel harness all-gathers over RCCL */
+pgk_status pgk_engine_state_ptr(pgk_engine e, void** tokens, void** positions);
 /* number of kernel launches one decode step enqueues (for reporting) */
 pgk_status pgk_engine_launches_per_step(pgk_engine e, int* n);
 

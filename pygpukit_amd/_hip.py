@@ -86,9 +86,11 @@ _PROTOS = {
     "pgk_engine_destroy": [_V], "pgk_engine_bytes": [_V, C.POINTER(_Z), C.POINTER(_Z)],
     "pgk_engine_prefill": [_V, _I, c_i32_p, _I, _I, _V, C.POINTER(_F), _V],
     "pgk_engine_set_state": [_V, c_i32_p, c_i32_p, _I, _V], "pgk_engine_decode_step": [_V, _I, _V],
+    "pgk_engine_profile_step": [_V, _I, _I, C.POINTER(_F), C.POINTER(_I), _V],
     "pgk_engine_capture": [_V, _I, _V], "pgk_engine_replay": [_V, _I, _V], "pgk_engine_logits_ptr": [_V, c_void_pp],
     "pgk_engine_read_tokens": [_V, c_i32_p, _I, _I, _V], "pgk_engine_reset_log": [_V, _V],
-    "pgk_engine_kv_ptr": [_V, _I, c_void_pp, c_void_pp], "pgk_engine_launches_per_step": [_V, C.POINTER(_I)],
+    "pgk_engine_read_clock": [_V, C.POINTER(C.c_uint64), _I, _V],
+    "pgk_engine_kv_ptr": [_V, _I, c_void_pp, c_void_pp], "pgk_engine_state_ptr": [_V, c_void_pp, c_void_pp], "pgk_engine_launches_per_step": [_V, C.POINTER(_I)],
     "pgk_comm_unique_id": [C.c_char_p], "pgk_comm_init": [c_void_pp, C.c_char_p, _I, _I], "pgk_comm_destroy": [_V],
     "pgk_comm_broadcast": [_V, _V, _Z, _I, _V], "pgk_comm_all_gather": [_V, _V, _V, _Z, _V],
     "pgk_comm_all_reduce_max_f64": [_V, _V, _I, _V], "pgk_comm_barrier": [_V, _V],
@@ -132,6 +134,7 @@ def call(name: str, *args):
         raise PgkError(f"{name} failed (status {st}): {msg.decode(errors='replace') if msg else ''}")
 
 
+import ctypes as C  # noqa: E402,F811  (re-export for callers that build ctypes arguments)
 _device_checked = False
 
 

@@ -68,15 +68,68 @@ struct DecodeState {
 template <class T, int D, int G>
 __device__ __forceinline__ void decode_walk(const T* kbase, const T* vbase, int c0, int c1, const float (&qf)[G][8],
                                             int lane, int wid, DecodeState<G>& st) {
-    constexpr int LPR = D / 8, PPW = 64 / LPR;
+    constexpr int LPR = D / 8, PPW = 64 / LPR, U = 4, STRIDE = 4 * PPW;
     const int grp = lane / LPR, sub = lane % LPR;
-    for (int p0 = c0 + wid * PPW; p0 < c1; p0 += 4 * PPW) {
-        const int pos = p0 + grp;
-        const bool valid = pos < c1;
-        const int pc = valid ? pos : c1 - 1;  // clamp: loads stay in bounds, result discarded
+    // U position-groups per trip: all 2*U 16-byte loads are issued before the first is consumed, so a
+    // short chunk costs ONE memory round trip instead of one per position.
+    for (int p0 = c0 + wid * PPW; p0 < c1; p0 += U * STRIDE) {
+        float kf[U][8], vf[U][8];
+        bool valid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pos = p0 + u * STRIDE + grp;
+            valid[u] = pos < c1;
+            const int pc = valid[u] ? pos : c1 - 1;  // clamp: loads stay in bounds, result discarded
+            KVLoad<T>::load8(kbase + (size_t)pc * D + sub * 8, kf[u]);
+            KVLoad<T>::load8(vbase + (size_t)pc * D + sub * 8, vf[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float s[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float d = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d = fmaf(qf[g][j], kf[u][j], d);
+#pragma unroll
+                for (int off = LPR / 2; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
+                s[g] = d;
+            }
+            if (valid[u]) st.update(s, vf[u]);  // lane-group uniform
+        }
+    }
+}
+
+// Two-phase form for bf16 caches: issue the raw 16-byte loads of U position-groups (addresses clamped to
+// `clamp_max`, so they can be issued before the context length is known), consume them later.
+template <int U> struct KVBatch { uint4 k[U], v[U]; };
+
+template <int D, int U>
+__device__ __forceinline__ void kv_issue(KVBatch<U>& kb, const bf16* kbase, const bf16* vbase, int p0, int clamp_max, int lane) {
+    constexpr int LPR = D / 8, PPW = 64 / LPR, STRIDE = 4 * PPW;
+    const int grp = lane / LPR, sub = lane % LPR;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int pc = min(p0 + u * STRIDE + grp, clamp_max);
+        kb.k[u] = *reinterpret_cast<const uint4*>(kbase + (size_t)pc * D + sub * 8);
+        kb.v[u] = *reinterpret_cast<const uint4*>(vbase + (size_t)pc * D + sub * 8);
+    }
+}
+
+template <int D, int G, int U>
+__device__ __forceinline__ void kv_consume(const KVBatch<U>& kb, int p0, int c1, const float (&qf)[G][8], int lane,
+                                           DecodeState<G>& st) {
+    constexpr int LPR = D / 8, PPW = 64 / LPR, STRIDE = 4 * PPW;
+    const int grp = lane / LPR;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool valid = p0 + u * STRIDE + grp < c1;
+        Vec<bf16> kv, vv;
+        kv.raw = kb.k[u];
+        vv.raw = kb.v[u];
         float kf[8], vf[8];
-        KVLoad<T>::load8(kbase + (size_t)pc * D + sub * 8, kf);
-        KVLoad<T>::load8(vbase + (size_t)pc * D + sub * 8, vf);
+        kv.to_float(kf);
+        vv.to_float(vf);
         float s[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -85,9 +138,9 @@ __device__ __forceinline__ void decode_walk(const T* kbase, const T* vbase, int 
             for (int j = 0; j < 8; ++j) d = fmaf(qf[g][j], kf[j], d);
 #pragma unroll
             for (int off = LPR / 2; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
-            s[g] = valid ? d : -INFINITY;
+            s[g] = d;
         }
-        if (valid) st.update(s, vf);  // lane-group uniform
+        if (valid) st.update(s, vf);
     }
 }
 
@@ -124,6 +177,40 @@ __device__ __forceinline__ void decode_block_merge(const DecodeState<G>& st, flo
         outrec[2 + d] = o;
         if (d == 0) { outrec[0] = mx; outrec[1] = l; }
     }
+}
+
+// Same merge, but the workgroup saw the WHOLE context: write the normalised attention output
+// attn[g*D + d] into LDS (`attn_out`, G*D floats) for a consumer inside the same kernel.
+template <int D, int G>
+__device__ __forceinline__ void decode_block_merge_lds(const DecodeState<G>& st, float* lds, float* attn_out, int lane,
+                                                       int wid) {
+    constexpr int LPR = D / 8, PPW = 64 / LPR, NS = 4 * PPW, RS = D + 2;
+    const int grp = lane / LPR, sub = lane % LPR;
+    const int slot = wid * PPW + grp;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float* rec = lds + ((size_t)slot * G + g) * RS;
+        if (sub == 0) { rec[0] = st.m[g]; rec[1] = st.l[g]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rec[2 + sub * 8 + j] = st.o[g][j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < G * D; e += blockDim.x) {
+        const int g = e / D, d = e % D;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) mx = fmaxf(mx, lds[((size_t)s * G + g) * RS]);
+        float l = 0.f, o = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float* rec = lds + ((size_t)s * G + g) * RS;
+            const float w = (rec[0] == -INFINITY) ? 0.f : __expf(rec[0] - mx);
+            l = fmaf(rec[1], w, l);
+            o = fmaf(rec[2 + d], w, o);
+        }
+        attn_out[e] = l > 0.f ? o / l : 0.f;
+    }
+    __syncthreads();
 }
 
 // Combine `nsplit` chunk records of one head into the normalised output element d.

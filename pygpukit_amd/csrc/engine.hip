@@ -1,25 +1,28 @@
 // Native decode / prefill engine for Qwen3 / Llama-shaped causal transformers on gfx950.
 //
-// Decode step = 5 fused weight-streaming kernels per layer + 3 per step, all enqueued by ONE C call
-// and captured into ONE hipGraph whose per-sequence token id and position live in device memory:
+// A decode step is a short chain of fused weight-streaming kernels, enqueued by ONE C call and captured
+// into ONE hipGraph whose per-sequence token id and position live in device memory:
 //
-//   embed                    h[b]            = E[token[b]]                         (fp32 residual stream)
-//   per layer
-//     norm_qkv               qkv[b]          = Wqkv . rmsnorm(h[b])
-//     attn                   partials        = split-KV attention; fuses QK-norm, RoPE, KV-cache write
-//     oproj_residual         h[b]           += Wo . combine(partials)
-//     norm_gateup_swiglu     act[b]          = silu(Wg . x) * (Wu . x),  x = rmsnorm(h[b])
-//     down_residual          h[b]           += Wd . act[b]
-//   norm_lmhead              logits[b]       = E . rmsnorm(h[b])  (+ per-workgroup argmax partials)
-//   argmax_finalize          token[b] = argmax (lowest index on ties), position[b] += 1, log token
+//   per layer (fused path, contexts <= 512):
+//     norm_qkv          qkv[b]      = Wqkv . rmsnorm(h[b])
+//     attn_oproj        part[b][kv] = Wo[:, heads of kv] . attention(q,k,v of kv head)   (QK-norm, RoPE, KV write inside)
+//     norm_gateup       h2[b] = h[b] + sum_kv part[b][kv] ;  act[b] = silu(Wg x) * (Wu x),  x = rmsnorm(h2[b])
+//     down_residual     h[b]  = h2[b] + Wd . act[b]
+//   per layer (split path, long contexts): norm_qkv, split-KV attn, oproj_residual, norm_gateup, down_residual
+//   norm_lmhead         logits[b]   = E . rmsnorm(h[b])  (+ per-workgroup argmax partials)
+//   finalize            token[b] = argmax (lowest index on ties); position[b] += 1; log; h[b] = E[token[b]]
 //
-// versus ~21 launches + 21 device syncs per layer in the reference's eager step and 2L+2 graphs in its
-// "graph" step (src/pygpukit/llm/decode/m1.py:40-121, m1_graph.py:463-589).
-// The residual stream, q/k/v and the MLP activation stay fp32 between kernels; only the KV cache
-// (bf16) and the weights are rounded.  KV cache layout: [layer][seq][Hkv][max_seq][D] - un-expanded GQA.
+// i.e. 4L+2 launches per token versus ~21 launches + 21 device syncs per layer in the reference's eager
+// step and 2L+2 graphs in its "graph" step (src/pygpukit/llm/decode/m1.py:40-121,
+// m1_graph.py:463-589).  On this chip a dependent kernel boundary (~1.7 us in a graph) is the cheapest
+// chip-wide synchronisation there is, so the design minimises the NUMBER of boundaries and, inside each
+// kernel, issues the weight loads BEFORE the activation prologue so the two memory round trips overlap.
+// The residual stream, q/k/v and the MLP activation stay fp32 between kernels; only the KV cache (bf16)
+// and the weights are rounded.  KV cache layout: [layer][seq][Hkv][max_seq][D] - un-expanded GQA.
 //
 // Prefill runs the MFMA GEMM / flash-attention kernels on bf16 activations with an fp32 residual stream.
 
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -35,19 +38,21 @@ pgk_status engine_gemm_nt(const bf16* A, const void* W, const bf16* wscale, bool
 // --------------------------------------------------------------------------------------------
 // Fused GEMV kernel: prologue builds x[M][K] in LDS, body streams W, epilogue consumes y.
 // --------------------------------------------------------------------------------------------
-enum { PRO_NORM = 0, PRO_PLAIN = 1, PRO_ATTN = 2 };
+enum { PRO_NORM = 0, PRO_PLAIN = 1, PRO_ATTN = 2, PRO_NORM_SUM = 3 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3 };
 
 struct FusedArgs {
     const void* w;        // [N,K] (SWIGLU: [2*N,K], gate rows then up rows)
     const bf16* wscale;   // fp8 block scales or null
     int N, K;
-    const float* h;       // PRO_NORM: [M][K] residual stream
+    const float* h;       // PRO_NORM / PRO_NORM_SUM: [M][K] residual stream
     const bf16* gamma;
     float eps;
     const float* xin;     // PRO_PLAIN: [M][K]
-    const float* part;    // PRO_ATTN: [M][Hq][nsplit][D+2]
-    int nsplit, hq, d;
+    const float* part;    // PRO_ATTN: [M][Hq][nsplit][D+2] ; PRO_NORM_SUM: [M][n_part][K]
+    int nsplit, hq, d;    // PRO_NORM_SUM: nsplit = number of partial vectors to add
+    float* h_out;         // PRO_NORM_SUM: workgroup 0 stores h + sum(part) here ([M][K])
+    const float* res;     // EPI_RESID: out = res + y (res may alias out)
     float* out;           // [M][ld_out]
     int ld_out;
     float* amax_val;      // EPI_LOGITS: [M][gridDim.x]
@@ -58,51 +63,165 @@ template <class XT> __device__ __forceinline__ void store_x(XT* xs, int i, float
 template <> __device__ __forceinline__ void store_x<float>(float* xs, int i, float v) { xs[i] = v; }
 template <> __device__ __forceinline__ void store_x<bf16>(bf16* xs, int i, float v) { xs[i] = from_f<bf16>(v); }
 
-template <class WT, class XT, int M, int R, int PRO, int EPI>
+// C = number of 16-byte chunks per weight row held per lane.  C > 0 fixes K = C * 64 * NW at COMPILE
+// time: the whole row set of the wave's first trip is preloaded before the prologue touches the
+// activations, and every prologue loop has an exact trip count - straight-line code, no guarded loads.
+// (A load under a per-lane guard, or accumulated inside a conditional, is waited for on the spot by
+// hipcc: that serialised dozens of memory round trips per kernel in the first version.)  C == 0 is the
+// generic any-K path.
+template <class WT, class XT, int M, int R, int PRO, int EPI, int C>
 __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a) {
+    constexpr int NW = WTraits<WT>::NW;
+    constexpr bool FP8 = std::is_same<WT, fp8e4m3>::value;
+    constexpr int KC = C * 64 * NW;           // compile-time K (0 = runtime)
+    constexpr int KJ = KC / 256;              // activation elements per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     XT* xs = reinterpret_cast<XT*>(smem);  // [M][K]
     __shared__ float red[16];
     __shared__ float s_bv[4][M];
     __shared__ int s_bi[4][M];
-    const int K = a.K, N = a.N;
+    const int K = (C > 0) ? KC : a.K;
+    const int N = a.N;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int OUT_PER_TRIP = (EPI == EPI_SWIGLU) ? R / 2 : R;
+    const int wave = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
 
-    // ---- prologue ----
-    if constexpr (PRO == PRO_NORM) {
+    auto row_of = [&](int n0, int r) -> int {
+        if constexpr (EPI == EPI_SWIGLU) return (r < R / 2) ? min(n0 + r, N - 1) : N + min(n0 + r - R / 2, N - 1);
+        else return min(n0 + r, N - 1);
+    };
+
+    uint4 pre[R][C > 0 ? C : 1];
+    float psc[R][C > 0 ? C : 1];
+    float resv[R][M];
+    if constexpr (C > 0) {
+        // ---- all global loads of the first trip, issued back to back ----
+        const int nf = min(wave * OUT_PER_TRIP, N - 1);  // waves beyond N recompute the last rows (never stored)
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const float* hr = a.h + (size_t)m * K;
-            float ss = 0.f;
-            for (int i = threadIdx.x; i < K; i += 256) { const float v = hr[i]; ss = fmaf(v, v, ss); }
-            ss = block_sum(ss, red);
-            const float inv = 1.0f / sqrtf(ss / K + a.eps);
-            for (int i = threadIdx.x; i < K; i += 256) store_x<XT>(xs, m * K + i, hr[i] * inv * to_f(a.gamma[i]));
-        }
-    } else if constexpr (PRO == PRO_PLAIN) {
-        for (int i = threadIdx.x; i < M * K; i += 256) store_x<XT>(xs, i, a.xin[i]);
-    } else {  // PRO_ATTN: K == hq * d
-        const int RS = a.d + 2;
-        for (int i = threadIdx.x; i < M * K; i += 256) {
-            const int m = i / K, e = i % K, hh = e / a.d, dd = e % a.d;
-            const float* recs = a.part + ((size_t)m * a.hq + hh) * a.nsplit * RS;
-            float mx = -INFINITY;
-            for (int s = 0; s < a.nsplit; ++s) mx = fmaxf(mx, recs[(size_t)s * RS]);
-            float l = 0.f, o = 0.f;
-            for (int s = 0; s < a.nsplit; ++s) {
-                const float* rec = recs + (size_t)s * RS;
-                const float w = (rec[0] == -INFINITY) ? 0.f : __expf(rec[0] - mx);
-                l = fmaf(rec[1], w, l);
-                o = fmaf(rec[2 + dd], w, o);
+        for (int r = 0; r < R; ++r) {
+            const int row = row_of(nf, r);
+            const WT* wr = reinterpret_cast<const WT*>(a.w) + (size_t)row * KC;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int k0 = lane * NW + c * 64 * NW;
+                pre[r][c] = load_nt16(wr + k0);
+                if constexpr (FP8) psc[r][c] = to_f(a.wscale[(size_t)(row >> 7) * (KC >> 7) + (k0 >> 7)]);
             }
-            store_x<XT>(xs, i, l > 0.f ? o / l : 0.f);
+        }
+        if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int m = 0; m < M; ++m) resv[r][m] = a.res[(size_t)m * a.ld_out + min(nf + r, N - 1)];
+        }
+        // ---- prologue, exact trip counts ----
+        if constexpr (PRO == PRO_NORM || PRO == PRO_NORM_SUM) {
+            constexpr int NP = (PRO == PRO_NORM_SUM) ? 8 : 1;
+            const int np = (PRO == PRO_NORM_SUM) ? a.nsplit : 1;
+            float hv[M][KJ], gv[KJ];
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) {
+                const int i = threadIdx.x + 256 * j;
+                gv[j] = to_f(a.gamma[i]);
+#pragma unroll
+                for (int m = 0; m < M; ++m) hv[m][j] = a.h[(size_t)m * KC + i];
+            }
+            if constexpr (PRO == PRO_NORM_SUM) {
+                // partial vectors: unconditional clamped loads, masked adds (one round trip for up to 8)
+#pragma unroll
+                for (int m = 0; m < M; ++m)
+#pragma unroll
+                    for (int j = 0; j < KJ; ++j) {
+                        float pv[NP];
+#pragma unroll
+                        for (int p = 0; p < NP; ++p)
+                            pv[p] = a.part[((size_t)m * np + min(p, np - 1)) * KC + threadIdx.x + 256 * j];
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) hv[m][j] += (p < np) ? pv[p] : 0.f;
+                    }
+            }
+            float ss[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                ss[m] = 0.f;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) ss[m] = fmaf(hv[m][j], hv[m][j], ss[m]);
+                ss[m] = wave_sum(ss[m]);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) s_bv[wid][m] = ss[m];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const float tot = s_bv[0][m] + s_bv[1][m] + s_bv[2][m] + s_bv[3][m];
+                const float inv = 1.0f / sqrtf(tot / KC + a.eps);
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    const int i = threadIdx.x + 256 * j;
+                    if constexpr (PRO == PRO_NORM_SUM) { if (blockIdx.x == 0) a.h_out[(size_t)m * KC + i] = hv[m][j]; }
+                    store_x<XT>(xs, m * KC + i, hv[m][j] * inv * gv[j]);
+                }
+            }
+        } else if constexpr (PRO == PRO_PLAIN) {
+            float xv[M][KJ];
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) xv[m][j] = a.xin[(size_t)m * KC + threadIdx.x + 256 * j];
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) store_x<XT>(xs, m * KC + threadIdx.x + 256 * j, xv[m][j]);
+        }
+    }
+    if constexpr (C == 0 || PRO == PRO_ATTN) {
+        // ---- generic prologue (any K) ----
+        if constexpr (PRO == PRO_NORM || PRO == PRO_NORM_SUM) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const float* hr = a.h + (size_t)m * K;
+                auto xin = [&](int i) -> float {
+                    float v = hr[i];
+                    if constexpr (PRO == PRO_NORM_SUM) {
+                        for (int p = 0; p < a.nsplit; ++p) v += a.part[((size_t)m * a.nsplit + p) * K + i];
+                    }
+                    return v;
+                };
+                float ss = 0.f;
+                for (int i = threadIdx.x; i < K; i += 256) { const float v = xin(i); ss = fmaf(v, v, ss); }
+                ss = block_sum(ss, red);
+                const float inv = 1.0f / sqrtf(ss / K + a.eps);
+                for (int i = threadIdx.x; i < K; i += 256) {
+                    const float v = xin(i);
+                    if constexpr (PRO == PRO_NORM_SUM) { if (blockIdx.x == 0) a.h_out[(size_t)m * K + i] = v; }
+                    store_x<XT>(xs, m * K + i, v * inv * to_f(a.gamma[i]));
+                }
+            }
+        } else if constexpr (PRO == PRO_PLAIN) {
+            for (int i = threadIdx.x; i < M * K; i += 256) store_x<XT>(xs, i, a.xin[i]);
+        } else {  // PRO_ATTN: K == hq * d ; merge the split-KV records
+            const int RS = a.d + 2;
+            for (int i = threadIdx.x; i < M * K; i += 256) {
+                const int m = i / K, e = i % K, hh = e / a.d, dd = e % a.d;
+                const float* recs = a.part + ((size_t)m * a.hq + hh) * a.nsplit * RS;
+                float mx = -INFINITY;
+                for (int s = 0; s < a.nsplit; ++s) mx = fmaxf(mx, recs[(size_t)s * RS]);
+                float l = 0.f, o = 0.f;
+                for (int s = 0; s < a.nsplit; ++s) {
+                    const float* rec = recs + (size_t)s * RS;
+                    const float w = (rec[0] == -INFINITY) ? 0.f : __expf(rec[0] - mx);
+                    l = fmaf(rec[1], w, l);
+                    o = fmaf(rec[2 + dd], w, o);
+                }
+                store_x<XT>(xs, i, l > 0.f ? o / l : 0.f);
+            }
         }
     }
     __syncthreads();
 
     // ---- body ----
-    constexpr int OUT_PER_TRIP = (EPI == EPI_SWIGLU) ? R / 2 : R;
-    const int wave = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
     float best_v[M];
     int best_i[M];
 #pragma unroll
@@ -110,23 +229,49 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a) {
 
     for (int g = wave; g * OUT_PER_TRIP < N; g += nwaves) {
         const int n0 = g * OUT_PER_TRIP;
-        const WT* wrow[R];
-        const bf16* srow[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            int row;
-            if constexpr (EPI == EPI_SWIGLU) row = (r < R / 2) ? min(n0 + r, N - 1) : N + min(n0 + r - R / 2, N - 1);
-            else row = min(n0 + r, N - 1);
-            wrow[r] = reinterpret_cast<const WT*>(a.w) + (size_t)row * K;
-            srow[r] = a.wscale ? a.wscale + (size_t)(row >> 7) * (K >> 7) : nullptr;
-        }
         float acc[R][M];
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
-        if constexpr (std::is_same<WT, fp8e4m3>::value) gemv_rows_fp8<XT, M, R>(wrow, srow, xs, K, K, lane, acc);
-        else gemv_rows<WT, XT, M, R>(wrow, xs, K, K, lane, acc);
+        if (C > 0 && g == wave) {
+            // consume the preloaded chunks
+#pragma unroll
+            for (int c = 0; c < (C > 0 ? C : 1); ++c) {
+                const int k0 = lane * NW + c * 64 * NW;
+                float xf[M][NW];
+#pragma unroll
+                for (int m = 0; m < M; ++m) XLoad<XT, NW>::load(xs + (size_t)m * K + k0, xf[m]);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float wf[NW];
+                    WTraits<WT>::decode(pre[r][c], wf);
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        if constexpr (FP8) {
+                            float p = 0.f;
+#pragma unroll
+                            for (int j = 0; j < NW; ++j) p = fmaf(wf[j], xf[m][j], p);
+                            acc[r][m] = fmaf(psc[r][c], p, acc[r][m]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < NW; ++j) acc[r][m] = fmaf(wf[j], xf[m][j], acc[r][m]);
+                        }
+                    }
+                }
+            }
+        } else {
+            const WT* wrow[R];
+            const bf16* srow[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int row = row_of(n0, r);
+                wrow[r] = reinterpret_cast<const WT*>(a.w) + (size_t)row * K;
+                srow[r] = a.wscale ? a.wscale + (size_t)(row >> 7) * (K >> 7) : nullptr;
+            }
+            if constexpr (FP8) gemv_rows_fp8<XT, M, R>(wrow, srow, xs, K, K, lane, acc);
+            else gemv_rows<WT, XT, M, R>(wrow, xs, K, K, lane, acc);
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -149,9 +294,13 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a) {
                     if (n0 + r < N) {
 #pragma unroll
                         for (int m = 0; m < M; ++m) {
-                            float* o = a.out + (size_t)m * a.ld_out + n0 + r;
-                            if constexpr (EPI == EPI_RESID) *o += acc[r][m];
-                            else *o = acc[r][m];
+                            const size_t o = (size_t)m * a.ld_out + n0 + r;
+                            if constexpr (EPI == EPI_RESID) {
+                                const float base = (C > 0 && g == wave) ? resv[r][m] : a.res[o];
+                                a.out[o] = base + acc[r][m];
+                            } else {
+                                a.out[o] = acc[r][m];
+                            }
                             if constexpr (EPI == EPI_LOGITS) {
                                 if (acc[r][m] > best_v[m]) { best_v[m] = acc[r][m]; best_i[m] = n0 + r; }
                             }
@@ -161,6 +310,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a) {
         }
     }
     if constexpr (EPI == EPI_LOGITS) {
+        __syncthreads();  // s_bv may still be read by the prologue reduction of a slower wave
         if (lane == 0) {
 #pragma unroll
             for (int m = 0; m < M; ++m) { s_bv[wid][m] = best_v[m]; s_bi[wid][m] = best_i[m]; }
@@ -178,19 +328,32 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a) {
     }
 }
 
-// h[b][:] = E[token[b]][:]
-__global__ void embed_kernel(const bf16* embed, const int32_t* tokens, float* h, int H) {
+// h[b][:] = E[token[b]][:]   (step entry: pgk_engine_set_state; afterwards finalize_kernel keeps h current)
+__global__ void embed_kernel(const bf16* embed, const int32_t* tokens, float* h, int H, const int32_t* positions,
+                             const float* rope_cos, const float* rope_sin, float* cur_cos, float* cur_sin, int half,
+                             int max_seq) {
     const int b = blockIdx.x;
     const bf16* row = embed + (size_t)tokens[b] * H;
     for (int i = threadIdx.x; i < H; i += blockDim.x) h[(size_t)b * H + i] = to_f(row[i]);
+    const int pos = min(positions[b], max_seq - 1);
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        cur_cos[(size_t)b * half + i] = rope_cos[(size_t)pos * half + i];
+        cur_sin[(size_t)b * half + i] = rope_sin[(size_t)pos * half + i];
+    }
 }
 
-// token[b] = argmax over workgroup partials (ties -> lowest index); position[b] += 1; log.
-__global__ void argmax_finalize_kernel(const float* amax_val, const int* amax_idx, int nblk, int32_t* tokens,
-                                       int32_t* positions, int32_t* token_log, int32_t* step_counter, int batch,
-                                       int log_cap) {
+// token[b] = argmax over workgroup partials (ties -> lowest index); position[b] += 1; log the token;
+// h[b] = E[token] for the next step; the last workgroup of the step bumps the step counter.
+__global__ __launch_bounds__(256) void finalize_kernel(const float* amax_val, const int* amax_idx, int nblk,
+                                                       int32_t* tokens, int32_t* positions, int32_t* token_log,
+                                                       int32_t* step_counter, int log_width, int log_cap,
+                                                       const bf16* embed, float* h, int H, int bump,
+                                                       unsigned long long* clk_log, const float* rope_cos,
+                                                       const float* rope_sin, float* cur_cos, float* cur_sin, int half,
+                                                       int max_seq) {
     __shared__ float sv[4];
     __shared__ int si[4];
+    __shared__ int s_tok, s_pos;
     const int b = blockIdx.x;
     float bv = -INFINITY;
     int bi = 0x7FFFFFFF;
@@ -209,114 +372,234 @@ __global__ void argmax_finalize_kernel(const float* amax_val, const int* amax_id
     if (lane == 0) { sv[wid] = bv; si[wid] = bi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int nw = blockDim.x >> 6;
-        for (int w = 1; w < nw; ++w)
+        for (int w = 1; w < 4; ++w)
             if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
         if (bi == 0x7FFFFFFF) bi = 0;
+        s_tok = bi;
         tokens[b] = bi;
-        positions[b] += 1;
+        const int npos = positions[b] + 1;
+        positions[b] = npos;
+        s_pos = min(npos, max_seq - 1);
         const int step = step_counter[0];
-        if (step < log_cap) token_log[(size_t)step * batch + b] = bi;
+        if (step < log_cap) token_log[(size_t)step * log_width + b] = bi;
+        if (b == 0 && step < log_cap && clk_log) {  // shader-clock / 100 MHz wall-clock stamps (diagnostic only)
+            clk_log[2 * (size_t)step] = __builtin_amdgcn_s_memtime();
+            clk_log[2 * (size_t)step + 1] = __builtin_amdgcn_s_memrealtime();
+        }
     }
+    __syncthreads();
+    const bf16* row = embed + (size_t)s_tok * H;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) h[(size_t)b * H + i] = to_f(row[i]);
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {  // RoPE row of the next position
+        cur_cos[(size_t)b * half + i] = rope_cos[(size_t)s_pos * half + i];
+        cur_sin[(size_t)b * half + i] = rope_sin[(size_t)s_pos * half + i];
+    }
+    if (bump && b == (int)gridDim.x - 1 && threadIdx.x == 0) step_counter[0] += 1;
 }
-__global__ void bump_step_kernel(int32_t* step_counter) { step_counter[0] += 1; }
 
 // --------------------------------------------------------------------------------------------
-// Decode attention with fused QK-norm + RoPE + KV-cache write.
-// grid (nsplit, Hkv, batch); qkv[b] = [q (Hq*D) | k (Hkv*D) | v (Hkv*D)] fp32, pre-norm.
+// Decode attention.  Shared front end: QK-norm + RoPE of the new token's q/k, bf16 rounding of k/v.
 // --------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const float* qkv;     // [B][(Hq+2Hkv)*D] fp32, pre-norm
+    int qkv_ld;
+    const bf16 *q_gamma, *k_gamma;
+    float eps;
+    const float *rope_cos, *rope_sin;   // [B][D/2]: the table rows of each sequence's CURRENT position
+    bf16 *kcache, *vcache;              // this layer: [B][Hkv][max_seq][D]
+    const int32_t* positions;
+    int hq, hkv, max_seq;
+    float scale;
+    // split path
+    float* part;          // [B][Hq][nsplit][D+2]
+    int nsplit;
+    // fused o_proj path
+    const bf16* w_o;      // [H][Hq*D]
+    int H, rows_per_block;
+    float* opart;         // [B][Hkv][H]
+};
+
 template <int D, int G>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const float* qkv, int qkv_ld, const bf16* q_gamma,
-                                                          const bf16* k_gamma, float eps, const float* rope_cos,
-                                                          const float* rope_sin, bf16* kcache, bf16* vcache,
-                                                          const int32_t* positions, float* part, int hq, int hkv,
-                                                          int max_seq, int nsplit, float scale) {
-    constexpr int LPR = D / 8, PPW = 64 / LPR, RS = D + 2, HALF = D / 2;
-    __shared__ float lds[4 * PPW * G * RS];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int sub = lane % LPR;
-    const int kvh = blockIdx.y, b = blockIdx.z;
-    const int pos = positions[b];                    // position of the token being decoded
-    const int ctx = min(pos + 1, max_seq);
-    const float* row = qkv + (size_t)b * qkv_ld;
-    const float* cs = rope_cos + (size_t)min(pos, max_seq - 1) * HALF;
-    const float* sn = rope_sin + (size_t)min(pos, max_seq - 1) * HALF;
+struct NewToken {
+    float qf[G][8], kn[8], vn[8];
+    uint4 kbits, vbits;
+};
 
-    // norm + rope of one head vector; this lane holds dims sub*8 .. +8, the rotate-half partner
-    // dims live LPR/2 lanes away.
-    auto norm_rope = [&](const float* src, const bf16* gamma, float (&o)[8]) {
+template <int D, int G>
+__device__ __forceinline__ void prepare_new_token(const AttnArgs& a, int b, int kvh, int pos, int lane, NewToken<D, G>& t) {
+    constexpr int LPR = D / 8, HALF = D / 2;
+    const int sub = lane % LPR;
+    const float* row = a.qkv + (size_t)b * a.qkv_ld;
+    const float* cs = a.rope_cos + (size_t)b * HALF;   // address independent of pos: no extra round trip
+    const float* sn = a.rope_sin + (size_t)b * HALF;
+    // all loads first (q heads, k, v, gammas, rope row): one memory round trip, then pure ALU
+    float raw[G + 2][8], gq[8], gk[8], csv[8], snv[8];
+#pragma unroll
+    for (int g = 0; g < G + 2; ++g) {
+        const float* src = (g < G) ? row + (size_t)(kvh * G + g) * D
+                                   : (g == G ? row + (size_t)a.hq * D + (size_t)kvh * D
+                                             : row + (size_t)(a.hq + a.hkv) * D + (size_t)kvh * D);
+        const float4 u = *reinterpret_cast<const float4*>(src + sub * 8), v = *reinterpret_cast<const float4*>(src + sub * 8 + 4);
+        raw[g][0] = u.x; raw[g][1] = u.y; raw[g][2] = u.z; raw[g][3] = u.w;
+        raw[g][4] = v.x; raw[g][5] = v.y; raw[g][6] = v.z; raw[g][7] = v.w;
+    }
+    const bool has_norm = a.q_gamma != nullptr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        gq[j] = has_norm ? to_f(a.q_gamma[sub * 8 + j]) : 1.f;
+        gk[j] = has_norm ? to_f(a.k_gamma[sub * 8 + j]) : 1.f;
+        const int dd = (sub * 8 + j) % HALF;
+        csv[j] = cs[dd];
+        snv[j] = sn[dd];
+    }
+    // norm + rope of one head vector; this lane holds dims sub*8..+8, the rotate-half partner dims live
+    // LPR/2 lanes away.
+    auto norm_rope = [&](const float (&xin)[8], const float (&gamma)[8], float (&o)[8]) {
         float x[8];
-        const float4 a = *reinterpret_cast<const float4*>(src + sub * 8), c = *reinterpret_cast<const float4*>(src + sub * 8 + 4);
-        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = c.w;
-        if (gamma) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = xin[j];
+        if (has_norm) {
             float ss = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) ss = fmaf(x[j], x[j], ss);
 #pragma unroll
             for (int off = LPR / 2; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
-            const float inv = 1.0f / sqrtf(ss / D + eps);
+            const float inv = 1.0f / sqrtf(ss / D + a.eps);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = x[j] * inv * to_f(gamma[sub * 8 + j]);
+            for (int j = 0; j < 8; ++j) x[j] = x[j] * inv * gamma[j];
         }
-        const bool lo = sub < LPR / 2;  // first half of the head dims
+        const bool lo = sub < LPR / 2;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float other = __shfl_xor(x[j], LPR / 2, 64);
-            const int dd = (sub * 8 + j) % HALF;
-            const float c_ = cs[dd], s_ = sn[dd];
-            // x0' = x0*c - x1*s ; x1' = x1*c + x0*s
-            o[j] = lo ? (x[j] * c_ - other * s_) : (x[j] * c_ + other * s_);
+            o[j] = lo ? (x[j] * csv[j] - other * snv[j]) : (x[j] * csv[j] + other * snv[j]);
         }
     };
-
-    float qf[G][8];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        norm_rope(row + (size_t)(kvh * G + g) * D, q_gamma, qf[g]);
+        norm_rope(raw[g], gq, t.qf[g]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[g][j] *= scale;
+        for (int j = 0; j < 8; ++j) t.qf[g][j] *= a.scale;
     }
-    float kn[8], vn[8];
-    norm_rope(row + (size_t)hq * D + (size_t)kvh * D, k_gamma, kn);
-    {
-        const float* vsrc = row + (size_t)(hq + hkv) * D + (size_t)kvh * D + sub * 8;
-        const float4 a = *reinterpret_cast<const float4*>(vsrc), c = *reinterpret_cast<const float4*>(vsrc + 4);
-        vn[0] = a.x; vn[1] = a.y; vn[2] = a.z; vn[3] = a.w; vn[4] = c.x; vn[5] = c.y; vn[6] = c.z; vn[7] = c.w;
-    }
-    // the cache holds bf16: use the rounded values for this step too (same as reading them back)
+    norm_rope(raw[G], gk, t.kn);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t.vn[j] = raw[G + 1][j];
+    // the cache holds bf16: this step uses the rounded values too (identical to reading them back)
     Vec<bf16> kb, vb;
-    kb.from_float(kn);
-    vb.from_float(vn);
-    kb.to_float(kn);
-    vb.to_float(vn);
+    kb.from_float(t.kn);
+    vb.from_float(t.vn);
+    kb.to_float(t.kn);
+    vb.to_float(t.vn);
+    t.kbits = kb.raw;
+    t.vbits = vb.raw;
+}
 
-    const size_t head_off = (((size_t)b * hkv + kvh) * max_seq) * D;
-    const int chunk = decode_chunk_len(ctx, nsplit);
-    const int c0 = min(blockIdx.x * chunk, ctx), c1 = min(c0 + chunk, ctx);
-    const bool owns_new = (pos < max_seq) && (pos >= c0) && (pos < c1);
+template <int D, int G>
+__device__ __forceinline__ void fold_new_token(const NewToken<D, G>& t, DecodeState<G>& st) {
+    constexpr int LPR = D / 8;
+    float s[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float dsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsum = fmaf(t.qf[g][j], t.kn[j], dsum);
+#pragma unroll
+        for (int off = LPR / 2; off >= 1; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
+        s[g] = dsum;
+    }
+    st.update(s, t.vn);
+}
+
+// split path: grid (nsplit, Hkv, batch)
+template <int D, int G>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
+    constexpr int LPR = D / 8, PPW = 64 / LPR, RS = D + 2;
+    __shared__ float lds[4 * PPW * G * RS];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane % LPR;
+    const int kvh = blockIdx.y, b = blockIdx.z;
+    const int pos = a.positions[b];
+    const int ctx = min(pos + 1, a.max_seq);
+    NewToken<D, G> t;
+    prepare_new_token<D, G>(a, b, kvh, pos, lane, t);
+    const size_t head_off = (((size_t)b * a.hkv + kvh) * a.max_seq) * D;
+    const int chunk = decode_chunk_len(ctx, a.nsplit);
+    const int c0 = min((int)blockIdx.x * chunk, ctx), c1 = min(c0 + chunk, ctx);
+    const bool owns_new = (pos < a.max_seq) && (pos >= c0) && (pos < c1);
     if (owns_new && wid == 0 && lane < LPR) {
-        kb.store(kcache + head_off + (size_t)pos * D + sub * 8);
-        vb.store(vcache + head_off + (size_t)pos * D + sub * 8);
+        *reinterpret_cast<uint4*>(a.kcache + head_off + (size_t)pos * D + sub * 8) = t.kbits;
+        *reinterpret_cast<uint4*>(a.vcache + head_off + (size_t)pos * D + sub * 8) = t.vbits;
     }
     DecodeState<G> st;
     st.init();
-    // cached positions of this chunk, excluding the token being written right now
-    decode_walk<bf16, D, G>(kcache + head_off, vcache + head_off, c0, owns_new ? min(c1, pos) : c1, qf, lane, wid, st);
-    if (owns_new && wid == 0 && lane < LPR) {  // lane-group 0 of wave 0 folds the new token from registers
-        float s[G];
+    decode_walk<bf16, D, G>(a.kcache + head_off, a.vcache + head_off, c0, owns_new ? min(c1, pos) : c1, t.qf, lane, wid, st);
+    if (owns_new && wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
+    decode_block_merge<D, G>(st, lds, a.part + (((size_t)b * a.hq + (size_t)kvh * G) * a.nsplit + blockIdx.x) * RS,
+                             (size_t)a.nsplit * RS, lane, wid);
+}
+
+// fused path: grid (H / rows_per_block, Hkv, batch).  Every workgroup of a KV head recomputes that
+// head's (short-context) attention from L2-resident K/V, then multiplies it with ITS slice of W_o
+// (rows_per_block output rows x G*D columns), whose loads were issued before anything else.
+template <int D, int G>
+__global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a) {
+    constexpr int LPR = D / 8, PPW = 64 / LPR, RS = D + 2;
+    constexpr int GD = G * D, LPW = GD / 8;          // lanes covering one W_o row slice
+    constexpr int RPP = 256 / LPW;                   // rows per pass of the workgroup
+    constexpr int PRE = 4;                           // preloaded passes
+    __shared__ float lds[4 * PPW * G * RS];
+    __shared__ __attribute__((aligned(16))) float attn[GD];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane % LPR;
+    const int kvh = blockIdx.y, b = blockIdx.z;
+    const int r0 = blockIdx.x * a.rows_per_block;
+    const int lr = threadIdx.x % LPW, rip = threadIdx.x / LPW;
+    const int npass = a.rows_per_block / RPP;
+    const bf16* wbase = a.w_o + (size_t)kvh * GD + lr * 8;
+    const int ldw = a.hq * D;
+    uint4 pre[PRE];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float dsum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dsum = fmaf(qf[g][j], kn[j], dsum);
-#pragma unroll
-            for (int off = LPR / 2; off >= 1; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
-            s[g] = dsum;
-        }
-        st.update(s, vn);
+    for (int p = 0; p < PRE; ++p)  // unconditional (clamped) so nothing waits on these until the GEMV
+        pre[p] = load_nt16(wbase + (size_t)(r0 + min(p, npass - 1) * RPP + rip) * ldw);
+
+    // first KV batch: 12 position-groups per wave = positions [0, 48*PPW); addresses do not depend on the
+    // context length (clamped), so these loads share the round trip of everything else in this kernel
+    constexpr int U0 = 12;
+    const size_t head_off = (((size_t)b * a.hkv + kvh) * a.max_seq) * D;
+    KVBatch<U0> kb0;
+    kv_issue<D, U0>(kb0, a.kcache + head_off, a.vcache + head_off, wid * PPW, a.max_seq - 1, lane);
+    const int pos = a.positions[b];
+    NewToken<D, G> t;
+    prepare_new_token<D, G>(a, b, kvh, pos, lane, t);
+    if (blockIdx.x == 0 && pos < a.max_seq && wid == 0 && lane < LPR) {
+        *reinterpret_cast<uint4*>(a.kcache + head_off + (size_t)pos * D + sub * 8) = t.kbits;
+        *reinterpret_cast<uint4*>(a.vcache + head_off + (size_t)pos * D + sub * 8) = t.vbits;
     }
-    decode_block_merge<D, G>(st, lds, part + (((size_t)b * hq + (size_t)kvh * G) * nsplit + blockIdx.x) * RS,
-                             (size_t)nsplit * RS, lane, wid);
+    DecodeState<G> st;
+    st.init();
+    const int c1 = min(pos, a.max_seq);
+    kv_consume<D, G, U0>(kb0, wid * PPW, c1, t.qf, lane, st);
+    if (c1 > U0 * 4 * PPW)
+        decode_walk<bf16, D, G>(a.kcache + head_off, a.vcache + head_off, U0 * 4 * PPW, c1, t.qf, lane, wid, st);
+    if (wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
+    decode_block_merge_lds<D, G>(st, lds, attn, lane, wid);
+
+    float xf[8];
+    {
+        const float4 u = *reinterpret_cast<const float4*>(attn + lr * 8), v = *reinterpret_cast<const float4*>(attn + lr * 8 + 4);
+        xf[0] = u.x; xf[1] = u.y; xf[2] = u.z; xf[3] = u.w; xf[4] = v.x; xf[5] = v.y; xf[6] = v.z; xf[7] = v.w;
+    }
+    float* outp = a.opart + ((size_t)b * a.hkv + kvh) * a.H;
+    for (int p = 0; p < npass; ++p) {
+        const int row = r0 + p * RPP + rip;
+        uint4 w = (p < PRE) ? pre[p < PRE ? p : 0] : load_nt16(wbase + (size_t)row * ldw);
+        float wf[8];
+        WTraits<bf16>::decode(w, wf);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf(wf[j], xf[j], acc);
+#pragma unroll
+        for (int off = LPW / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lr == 0) outp[row] = acc;
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -437,17 +720,46 @@ __global__ void bf16_rows_to_f32_kernel(const bf16* in, float* out, size_t n) {
 }
 
 // --------------------------------------------------------------------------------------------
+// Optional per-kernel-class timing of an EAGER step: a hipEvent is recorded on the launch stream after
+// every kernel; class time = event[i+1] - event[i] (kernel + its launch gap).  Used by bench.py for the
+// `roofline` object; rocprofv3 --kernel-trace gives the gap-free durations (profiles/).
+enum { KC_EMBED = 0, KC_NORM_QKV, KC_ATTN, KC_OPROJ, KC_GATEUP, KC_DOWN, KC_LMHEAD, KC_ARGMAX, KC_COUNT };
+struct KernelTimer {
+    std::vector<hipEvent_t> ev;
+    std::vector<int> cls;
+    size_t used = 0;
+};
+static thread_local KernelTimer* g_timer = nullptr;
+static inline void mark(int cls, hipStream_t st) {
+    KernelTimer* t = g_timer;
+    if (!t) return;
+    if (t->used >= t->ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        t->ev.push_back(e);
+        t->cls.push_back(cls);
+    }
+    t->cls[t->used] = cls;
+    (void)hipEventRecord(t->ev[t->used], st);
+    ++t->used;
+}
+
 struct Engine {
     pgk_model_config_t cfg;
     const bf16 *embed, *lm_head, *final_norm;
     std::vector<pgk_layer_weights_t> layers;
     int nsplit = 1, lm_blocks = 1, log_cap = 4096;
+    int skip_attn = 0;         // PGK_DEBUG_SKIP & 16: do not launch attention at all (timing ablation)
+    bool fused_attn = false;   // attn + o_proj in one kernel (short contexts, bf16 W_o)
+    int oproj_rows = 32;       // W_o rows per workgroup on the fused path
     // device state
     bf16 *kcache = nullptr, *vcache = nullptr;
-    float *rope_cos = nullptr, *rope_sin = nullptr;
+    float *rope_cos = nullptr, *rope_sin = nullptr, *cur_cos = nullptr, *cur_sin = nullptr;
     int32_t *tokens = nullptr, *positions = nullptr, *token_log = nullptr, *step_counter = nullptr;
-    float *h = nullptr, *qkv = nullptr, *part = nullptr, *act = nullptr, *logits = nullptr, *amax_val = nullptr;
+    float *h = nullptr, *h2 = nullptr, *qkv = nullptr, *part = nullptr, *opart = nullptr, *act = nullptr, *logits = nullptr,
+          *amax_val = nullptr;
     int* amax_idx = nullptr;
+    unsigned long long* clk_log = nullptr;
     size_t kv_bytes = 0, ws_bytes = 0;
     // prefill workspace (grown on demand, outside capture)
     void* pf = nullptr;
@@ -473,12 +785,12 @@ static pgk_status dev_alloc(Engine* e, void** p, size_t bytes, size_t* acct) {
     return PGK_OK;
 }
 
-template <class WT, class XT, int M, int R, int PRO, int EPI>
-static pgk_status launch_fused(const FusedArgs& a, int n_out, hipStream_t st, int force_grid = 0) {
+template <class WT, class XT, int M, int R, int PRO, int EPI, int C>
+static pgk_status launch_fused_c(const FusedArgs& a, int n_out, hipStream_t st, int force_grid) {
     constexpr int OUT_PER_TRIP = (EPI == EPI_SWIGLU) ? R / 2 : R;
     const size_t lds = (size_t)M * a.K * sizeof(XT);
     PGK_REQUIRE(lds <= 156 * 1024, "engine: %d activation rows of K=%d do not fit LDS", M, a.K);
-    auto kfn = &fused_gemv_kernel<WT, XT, M, R, PRO, EPI>;
+    auto kfn = &fused_gemv_kernel<WT, XT, M, R, PRO, EPI, C>;
     static bool attr_done = false;
     if (lds > 48 * 1024 && !attr_done) {
         PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
@@ -491,16 +803,30 @@ static pgk_status launch_fused(const FusedArgs& a, int n_out, hipStream_t st, in
     return PGK_OK;
 }
 
+// Pick the preload depth C = K / (64 * NW) when the row is short enough to sit in registers.
+template <class WT, class XT, int M, int R, int PRO, int EPI>
+static pgk_status launch_fused(const FusedArgs& a, int n_out, hipStream_t st, int force_grid = 0) {
+    constexpr int NW = WTraits<WT>::NW;
+    const int c = (a.K % (64 * NW) == 0) ? a.K / (64 * NW) : 0;
+    constexpr int BUDGET = (M > 4 ? 4 : 8) / R;  // R*C*4 preload VGPRs: <= 32 (16 at large M)
+    if constexpr (1 <= BUDGET) { if (c == 1) return launch_fused_c<WT, XT, M, R, PRO, EPI, 1>(a, n_out, st, force_grid); }
+    if constexpr (2 <= BUDGET) { if (c == 2) return launch_fused_c<WT, XT, M, R, PRO, EPI, 2>(a, n_out, st, force_grid); }
+    if constexpr (3 <= BUDGET) { if (c == 3) return launch_fused_c<WT, XT, M, R, PRO, EPI, 3>(a, n_out, st, force_grid); }
+    if constexpr (4 <= BUDGET) { if (c == 4) return launch_fused_c<WT, XT, M, R, PRO, EPI, 4>(a, n_out, st, force_grid); }
+    if constexpr (6 <= BUDGET) { if (c == 6) return launch_fused_c<WT, XT, M, R, PRO, EPI, 6>(a, n_out, st, force_grid); }
+    return launch_fused_c<WT, XT, M, R, PRO, EPI, 0>(a, n_out, st, force_grid);
+}
+
 // rows-per-wave heuristic: enough workgroups to cover 256 CUs even for the N = hidden projections
 template <class WT, class XT, int M, int PRO, int EPI>
-static pgk_status launch_fused_auto(const FusedArgs& a, int n_out, hipStream_t st, int force_grid = 0) {
+static pgk_status launch_fused_auto(const FusedArgs& a, int n_out, hipStream_t st) {
     if constexpr (EPI == EPI_SWIGLU) {
-        if (n_out >= 4096) return launch_fused<WT, XT, M, 4, PRO, EPI>(a, n_out, st, force_grid);
-        return launch_fused<WT, XT, M, 2, PRO, EPI>(a, n_out, st, force_grid);
+        if (n_out >= 4096) return launch_fused<WT, XT, M, 4, PRO, EPI>(a, n_out, st);
+        return launch_fused<WT, XT, M, 2, PRO, EPI>(a, n_out, st);
     } else {
-        if (n_out >= 4096) return launch_fused<WT, XT, M, 4, PRO, EPI>(a, n_out, st, force_grid);
-        if (n_out >= 2048) return launch_fused<WT, XT, M, 2, PRO, EPI>(a, n_out, st, force_grid);
-        return launch_fused<WT, XT, M, 1, PRO, EPI>(a, n_out, st, force_grid);
+        if (n_out >= 4096) return launch_fused<WT, XT, M, 4, PRO, EPI>(a, n_out, st);
+        if (n_out >= 2048) return launch_fused<WT, XT, M, 2, PRO, EPI>(a, n_out, st);
+        return launch_fused<WT, XT, M, 1, PRO, EPI>(a, n_out, st);
     }
 }
 
@@ -510,17 +836,26 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, hipStream_t s
     const auto& L = e->layers[layer];
     const int G = c.num_heads / c.num_kv_heads;
     const size_t lofs = (size_t)layer * e->kv_layer_elems() + (size_t)b0 * c.num_kv_heads * c.max_seq_len * c.head_dim;
-    dim3 grid(e->nsplit, c.num_kv_heads, m);
-    const float scale = 1.0f / sqrtf((float)D);
-    const float* qkv = e->qkv + (size_t)b0 * e->qkv_dim();
-    float* part = e->part + (size_t)b0 * c.num_heads * e->nsplit * (D + 2);
-    const bf16* qg = c.use_qk_norm ? (const bf16*)L.q_norm : nullptr;
-    const bf16* kg = c.use_qk_norm ? (const bf16*)L.k_norm : nullptr;
-#define PGK_ATTN(GG)                                                                                                   \
-    case GG:                                                                                                           \
-        attn_decode_kernel<D, GG><<<grid, 256, 0, st>>>(qkv, e->qkv_dim(), qg, kg, c.norm_eps, e->rope_cos, e->rope_sin, \
-                                                        e->kcache + lofs, e->vcache + lofs, e->positions + b0, part,  \
-                                                        c.num_heads, c.num_kv_heads, c.max_seq_len, e->nsplit, scale); \
+    AttnArgs a{};
+    a.qkv = e->qkv + (size_t)b0 * e->qkv_dim();
+    a.qkv_ld = e->qkv_dim();
+    a.q_gamma = c.use_qk_norm ? (const bf16*)L.q_norm : nullptr;
+    a.k_gamma = c.use_qk_norm ? (const bf16*)L.k_norm : nullptr;
+    a.eps = c.norm_eps;
+    a.rope_cos = e->cur_cos + (size_t)b0 * (D / 2); a.rope_sin = e->cur_sin + (size_t)b0 * (D / 2);
+    a.kcache = e->kcache + lofs; a.vcache = e->vcache + lofs;
+    a.positions = e->positions + b0;
+    a.hq = c.num_heads; a.hkv = c.num_kv_heads; a.max_seq = c.max_seq_len;
+    a.scale = 1.0f / sqrtf((float)D);
+    a.part = e->part + (size_t)b0 * c.num_heads * e->nsplit * (D + 2);
+    a.nsplit = e->nsplit;
+    a.w_o = (const bf16*)L.w_o; a.H = c.hidden_size; a.rows_per_block = e->oproj_rows;
+    a.opart = e->opart ? e->opart + (size_t)b0 * c.num_kv_heads * c.hidden_size : nullptr;
+    dim3 grid = e->fused_attn ? dim3(c.hidden_size / e->oproj_rows, c.num_kv_heads, m) : dim3(e->nsplit, c.num_kv_heads, m);
+#define PGK_ATTN(GG)                                                               \
+    case GG:                                                                       \
+        if (e->fused_attn) attn_oproj_kernel<D, GG><<<grid, 256, 0, st>>>(a);      \
+        else attn_decode_kernel<D, GG><<<grid, 256, 0, st>>>(a);                   \
         break;
     switch (G) {
         PGK_ATTN(1) PGK_ATTN(2) PGK_ATTN(4)
@@ -531,15 +866,14 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, hipStream_t s
     return PGK_OK;
 }
 
-// One decode step for sequences [b0, b0+M)
+// One decode step for sequences [b0, b0+M); `last` = this is the step's last chunk (bumps the step counter)
 template <class WT, class XT, int M>
-static pgk_status decode_chunk(Engine* e, int b0, hipStream_t st, int* launches) {
+static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int* launches) {
     const auto& c = e->cfg;
     const int H = c.hidden_size, I = c.intermediate_size, D = c.head_dim, QD = c.num_heads * D, NQKV = e->qkv_dim();
     float* h = e->h + (size_t)b0 * H;
-    embed_kernel<<<M, 256, 0, st>>>(e->embed, e->tokens + b0, h, H);
-    PGK_CHECK_HIP(hipGetLastError());
-    ++*launches;
+    float* h2 = e->h2 + (size_t)b0 * H;
+    mark(-1, st);  // time origin
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& L = e->layers[l];
         FusedArgs a{};
@@ -548,28 +882,45 @@ static pgk_status decode_chunk(Engine* e, int b0, hipStream_t st, int* launches)
         a.h = h; a.gamma = (const bf16*)L.attn_norm; a.eps = c.norm_eps;
         a.out = e->qkv + (size_t)b0 * NQKV; a.ld_out = NQKV;
         if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM, EPI_STORE>(a, NQKV, st)) return r;
-        // 2. attention (QK-norm, RoPE, KV write fused)
-        if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, st)) return r; }
-        else { if (pgk_status r = launch_attn<64>(e, l, b0, M, st)) return r; }
-        // 3. h += Wo . attn
-        a = FusedArgs{};
-        a.w = L.w_o; a.wscale = (const bf16*)L.s_o; a.N = H; a.K = QD;
-        a.part = e->part + (size_t)b0 * c.num_heads * e->nsplit * (D + 2); a.nsplit = e->nsplit; a.hq = c.num_heads; a.d = D;
-        a.out = h; a.ld_out = H;
-        if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_ATTN, EPI_RESID>(a, H, st)) return r;
-        // 4. act = silu(Wg x) * (Wu x), x = rmsnorm(h)
+        mark(KC_NORM_QKV, st);
+        // 2. attention (QK-norm, RoPE, KV write fused; on the fused path also the o_proj partial products)
+        if (!e->skip_attn) {
+            if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, st)) return r; }
+            else { if (pgk_status r = launch_attn<64>(e, l, b0, M, st)) return r; }
+        }
+        mark(KC_ATTN, st);
+        const float* mlp_in = h;
+        if (!e->fused_attn) {
+            // 3. h += Wo . attn
+            a = FusedArgs{};
+                a.w = L.w_o; a.wscale = (const bf16*)L.s_o; a.N = H; a.K = QD;
+            a.part = e->part + (size_t)b0 * c.num_heads * e->nsplit * (D + 2); a.nsplit = e->nsplit; a.hq = c.num_heads; a.d = D;
+            a.res = h; a.out = h; a.ld_out = H;
+            if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_ATTN, EPI_RESID>(a, H, st)) return r;
+            mark(KC_OPROJ, st);
+            ++*launches;
+        }
+        // 4. act = silu(Wg x) * (Wu x), x = rmsnorm(h [+ sum of o_proj partials])
         a = FusedArgs{};
         a.w = L.w_gate_up; a.wscale = (const bf16*)L.s_gate_up; a.N = I; a.K = H;
         a.h = h; a.gamma = (const bf16*)L.mlp_norm; a.eps = c.norm_eps;
         a.out = e->act + (size_t)b0 * I; a.ld_out = I;
-        if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM, EPI_SWIGLU>(a, I, st)) return r;
-        // 5. h += Wd . act
+        if (e->fused_attn) {
+            a.part = e->opart + (size_t)b0 * c.num_kv_heads * H; a.nsplit = c.num_kv_heads; a.h_out = h2;
+            if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM_SUM, EPI_SWIGLU>(a, I, st)) return r;
+            mlp_in = h2;
+        } else {
+            if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM, EPI_SWIGLU>(a, I, st)) return r;
+        }
+        mark(KC_GATEUP, st);
+        // 5. h = mlp_in + Wd . act
         a = FusedArgs{};
         a.w = L.w_down; a.wscale = (const bf16*)L.s_down; a.N = H; a.K = I;
         a.xin = e->act + (size_t)b0 * I;
-        a.out = h; a.ld_out = H;
+        a.res = mlp_in; a.out = h; a.ld_out = H;
         if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_PLAIN, EPI_RESID>(a, H, st)) return r;
-        *launches += 5;
+        mark(KC_DOWN, st);
+        *launches += 4;
     }
     // logits = E . rmsnorm(h)  (lm_head stays bf16 even when the linears are fp8)
     FusedArgs a{};
@@ -578,10 +929,14 @@ static pgk_status decode_chunk(Engine* e, int b0, hipStream_t st, int* launches)
     a.out = e->logits + (size_t)b0 * c.vocab_size; a.ld_out = c.vocab_size;
     a.amax_val = e->amax_val + (size_t)b0 * e->lm_blocks; a.amax_idx = e->amax_idx + (size_t)b0 * e->lm_blocks;
     if (pgk_status r = launch_fused<bf16, XT, M, 4, PRO_NORM, EPI_LOGITS>(a, c.vocab_size, st, e->lm_blocks)) return r;
-    argmax_finalize_kernel<<<M, 256, 0, st>>>(e->amax_val + (size_t)b0 * e->lm_blocks, e->amax_idx + (size_t)b0 * e->lm_blocks,
-                                              e->lm_blocks, e->tokens + b0, e->positions + b0, e->token_log + b0,
-                                              e->step_counter, e->cfg.max_batch, e->log_cap);
+    mark(KC_LMHEAD, st);
+    finalize_kernel<<<M, 256, 0, st>>>(e->amax_val + (size_t)b0 * e->lm_blocks, e->amax_idx + (size_t)b0 * e->lm_blocks,
+                                       e->lm_blocks, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
+                                       e->cfg.max_batch, e->log_cap, e->embed, h, H, last ? 1 : 0, b0 == 0 ? e->clk_log : nullptr,
+                                       e->rope_cos, e->rope_sin, e->cur_cos + (size_t)b0 * (D / 2), e->cur_sin + (size_t)b0 * (D / 2),
+                                       D / 2, c.max_seq_len);
     PGK_CHECK_HIP(hipGetLastError());
+    mark(KC_ARGMAX, st);
     *launches += 2;
     return PGK_OK;
 }
@@ -592,15 +947,12 @@ static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* la
     while (b0 < batch) {
         const int rem = batch - b0;
         pgk_status r;
-        if (rem >= 8) { r = decode_chunk<WT, bf16, 8>(e, b0, st, launches); b0 += 8; }
-        else if (rem >= 4) { r = decode_chunk<WT, bf16, 4>(e, b0, st, launches); b0 += 4; }
-        else if (rem >= 2) { r = decode_chunk<WT, float, 2>(e, b0, st, launches); b0 += 2; }
-        else { r = decode_chunk<WT, float, 1>(e, b0, st, launches); b0 += 1; }
+        if (rem >= 8) { r = decode_chunk<WT, bf16, 8>(e, b0, rem == 8, st, launches); b0 += 8; }
+        else if (rem >= 4) { r = decode_chunk<WT, bf16, 4>(e, b0, rem == 4, st, launches); b0 += 4; }
+        else if (rem >= 2) { r = decode_chunk<WT, float, 2>(e, b0, rem == 2, st, launches); b0 += 2; }
+        else { r = decode_chunk<WT, float, 1>(e, b0, true, st, launches); b0 += 1; }
         if (r != PGK_OK) return r;
     }
-    bump_step_kernel<<<1, 1, 0, st>>>(e->step_counter);
-    PGK_CHECK_HIP(hipGetLastError());
-    ++*launches;
     return PGK_OK;
 }
 
@@ -633,9 +985,21 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
     e->lm_head = (const bf16*)(lm_head ? lm_head : embed);
     e->final_norm = (const bf16*)final_norm;
     e->layers.assign(layers, layers + c.num_layers);
-    int nsplit = (c.max_seq_len + 255) / 256;
+    int nsplit = (c.max_seq_len + 127) / 128;
     e->nsplit = nsplit < 1 ? 1 : (nsplit > 32 ? 32 : nsplit);
     e->lm_blocks = 1024;
+    // fused attention + o_proj: short contexts, bf16 W_o, and a row slicing that tiles the workgroup
+    {
+        const int gd = G * c.head_dim, rpp = 256 / (gd / 8);
+        int rows = c.hidden_size / 32;
+        while (rows > 4 * rpp && rows % 2 == 0) rows /= 2;   // <= 4 preloaded passes per workgroup
+        const bool tiles = rows % rpp == 0 && c.hidden_size % rows == 0 && gd / 8 <= 64;
+        if (const char* dbg = getenv("PGK_DEBUG_SKIP")) e->skip_attn = atoi(dbg) & 16;  // timing ablation only
+        const char* env = getenv("PGK_FUSED_ATTN");
+        const bool want = env ? atoi(env) != 0 : true;
+        e->fused_attn = want && tiles && c.weight_format == 0 && c.max_seq_len <= 512;
+        e->oproj_rows = rows;
+    }
     const int B = c.max_batch, H = c.hidden_size, D = c.head_dim;
     pgk_status r = PGK_OK;
     auto A = [&](void** p, size_t bytes, size_t* acct) { if (r == PGK_OK) r = dev_alloc(e, p, bytes, acct); };
@@ -644,17 +1008,22 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
     A((void**)&e->vcache, kvb, &e->kv_bytes);
     A((void**)&e->rope_cos, (size_t)c.max_seq_len * (D / 2) * 4, &e->ws_bytes);
     A((void**)&e->rope_sin, (size_t)c.max_seq_len * (D / 2) * 4, &e->ws_bytes);
+    A((void**)&e->cur_cos, (size_t)B * (D / 2) * 4, &e->ws_bytes);
+    A((void**)&e->cur_sin, (size_t)B * (D / 2) * 4, &e->ws_bytes);
     A((void**)&e->tokens, (size_t)B * 4, &e->ws_bytes);
     A((void**)&e->positions, (size_t)B * 4, &e->ws_bytes);
     A((void**)&e->token_log, (size_t)e->log_cap * B * 4, &e->ws_bytes);
     A((void**)&e->step_counter, 16, &e->ws_bytes);
     A((void**)&e->h, (size_t)B * H * 4, &e->ws_bytes);
+    A((void**)&e->h2, (size_t)B * H * 4, &e->ws_bytes);
     A((void**)&e->qkv, (size_t)B * e->qkv_dim() * 4, &e->ws_bytes);
     A((void**)&e->part, (size_t)B * c.num_heads * e->nsplit * (D + 2) * 4, &e->ws_bytes);
+    A((void**)&e->opart, (size_t)B * c.num_kv_heads * H * 4, &e->ws_bytes);
     A((void**)&e->act, (size_t)B * c.intermediate_size * 4, &e->ws_bytes);
     A((void**)&e->logits, (size_t)B * c.vocab_size * 4, &e->ws_bytes);
     A((void**)&e->amax_val, (size_t)B * e->lm_blocks * 4, &e->ws_bytes);
     A((void**)&e->amax_idx, (size_t)B * e->lm_blocks * 4, &e->ws_bytes);
+    A((void**)&e->clk_log, (size_t)e->log_cap * 16, &e->ws_bytes);
     if (r != PGK_OK) { pgk_engine_destroy(e); return r; }
     // RoPE tables in fp32, same formula as the reference (src/pygpukit/llm/layers/rope.py:13-24):
     // freqs = 1/theta^(2i/D) in fp32, angle = float(t) * freq in fp32, cos/sin of that.
@@ -677,6 +1046,7 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         if (he == hipSuccess) he = hipMemsetAsync(e->tokens, 0, (size_t)B * 4, st);
         if (he == hipSuccess) he = hipMemsetAsync(e->positions, 0, (size_t)B * 4, st);
         if (he == hipSuccess) he = hipMemsetAsync(e->step_counter, 0, 16, st);
+        if (he == hipSuccess) he = hipMemsetAsync(e->h, 0, (size_t)B * H * 4, st);
         if (he == hipSuccess) he = hipStreamSynchronize(st);
         if (he != hipSuccess) { pgk_engine_destroy(e); return set_error(PGK_ERR_HIP, "pgk_engine_create: %s", hipGetErrorString(he)); }
     }
@@ -805,6 +1175,10 @@ pgk_status pgk_engine_set_state(pgk_engine eh, const int32_t* h_tokens, const in
     hipStream_t st = resolve_stream(s);
     PGK_CHECK_HIP(hipMemcpyAsync(e->tokens, h_tokens, (size_t)batch * 4, hipMemcpyHostToDevice, st));
     PGK_CHECK_HIP(hipMemcpyAsync(e->positions, h_positions, (size_t)batch * 4, hipMemcpyHostToDevice, st));
+    // the residual stream enters a step already holding the embeddings of the state tokens
+    embed_kernel<<<batch, 256, 0, st>>>(e->embed, e->tokens, e->h, e->cfg.hidden_size, e->positions, e->rope_cos, e->rope_sin,
+                                        e->cur_cos, e->cur_sin, e->cfg.head_dim / 2, e->cfg.max_seq_len);
+    PGK_LAUNCH_CHECK();
     PGK_CHECK_HIP(hipStreamSynchronize(st));
     return PGK_OK;
 }
@@ -816,6 +1190,36 @@ pgk_status pgk_engine_decode_step(pgk_engine eh, int batch, pgk_stream s) {
     int launches = 0;
     pgk_status r = decode_step(e, batch, resolve_stream(s), &launches);
     e->launches_per_step = launches;
+    return r;
+}
+
+pgk_status pgk_engine_profile_step(pgk_engine eh, int batch, int n_iters, float* h_ms_sum, int* h_count, pgk_stream s) {
+    PGK_REQUIRE(eh && h_ms_sum && h_count, "pgk_engine_profile_step: null argument");
+    Engine* e = (Engine*)eh;
+    PGK_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch && n_iters >= 1, "pgk_engine_profile_step: bad arguments");
+    hipStream_t st = resolve_stream(s);
+    for (int i = 0; i < KC_COUNT; ++i) { h_ms_sum[i] = 0.f; h_count[i] = 0; }
+    KernelTimer timer;
+    pgk_status r = PGK_OK;
+    for (int it = 0; it < n_iters && r == PGK_OK; ++it) {
+        timer.used = 0;
+        g_timer = &timer;
+        int launches = 0;
+        r = decode_step(e, batch, st, &launches);
+        g_timer = nullptr;
+        if (r != PGK_OK) break;
+        hipError_t he = hipStreamSynchronize(st);
+        if (he != hipSuccess) { r = set_error(PGK_ERR_HIP, "pgk_engine_profile_step: %s", hipGetErrorString(he)); break; }
+        for (size_t i = 1; i < timer.used; ++i) {
+            if (timer.cls[i] < 0) continue;  // origin marker of the next chunk
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, timer.ev[i - 1], timer.ev[i]) == hipSuccess) {
+                h_ms_sum[timer.cls[i]] += ms;
+                h_count[timer.cls[i]] += 1;
+            }
+        }
+    }
+    for (hipEvent_t ev : timer.ev) (void)hipEventDestroy(ev);
     return r;
 }
 
@@ -872,6 +1276,18 @@ pgk_status pgk_engine_read_tokens(pgk_engine eh, int32_t* h_out, int batch, int 
     return PGK_OK;
 }
 
+pgk_status pgk_engine_read_clock(pgk_engine eh, uint64_t* h_out, int n_steps, pgk_stream s) {
+    PGK_REQUIRE(eh && h_out, "pgk_engine_read_clock: null argument");
+    Engine* e = (Engine*)eh;
+    PGK_REQUIRE(n_steps >= 0 && n_steps <= e->log_cap, "pgk_engine_read_clock: %d steps exceed the log capacity %d", n_steps, e->log_cap);
+    hipStream_t st = resolve_stream(s);
+    if (n_steps) {
+        PGK_CHECK_HIP(hipMemcpyAsync(h_out, e->clk_log, (size_t)n_steps * 16, hipMemcpyDeviceToHost, st));
+        PGK_CHECK_HIP(hipStreamSynchronize(st));
+    }
+    return PGK_OK;
+}
+
 pgk_status pgk_engine_reset_log(pgk_engine eh, pgk_stream s) {
     PGK_REQUIRE(eh, "pgk_engine_reset_log: null engine");
     PGK_CHECK_HIP(hipMemsetAsync(((Engine*)eh)->step_counter, 0, 16, resolve_stream(s)));
@@ -884,6 +1300,13 @@ pgk_status pgk_engine_kv_ptr(pgk_engine eh, int layer, void** k, void** v) {
     PGK_REQUIRE(layer >= 0 && layer < e->cfg.num_layers, "pgk_engine_kv_ptr: layer %d", layer);
     *k = e->kcache + (size_t)layer * e->kv_layer_elems();
     *v = e->vcache + (size_t)layer * e->kv_layer_elems();
+    return PGK_OK;
+}
+
+pgk_status pgk_engine_state_ptr(pgk_engine eh, void** tokens, void** positions) {
+    PGK_REQUIRE(eh && tokens && positions, "pgk_engine_state_ptr: null argument");
+    *tokens = ((Engine*)eh)->tokens;
+    *positions = ((Engine*)eh)->positions;
     return PGK_OK;
 }
 

@@ -89,6 +89,15 @@ class Engine:
         """Enqueue one eager (un-captured) step."""
         _hip.call("pgk_engine_decode_step", self.handle, batch, None)
 
+    KERNEL_CLASSES = ("embed", "norm_qkv", "attn", "oproj", "gateup", "down", "lmhead", "argmax")
+
+    def profile_step(self, batch: int = 1, n_iters: int = 8) -> dict:
+        """Eager steps with an event after every kernel -> {class: (avg_us_per_launch, launches_per_step)}."""
+        ms = (C.c_float * 8)()
+        cnt = (C.c_int * 8)()
+        _hip.call("pgk_engine_profile_step", self.handle, batch, n_iters, ms, cnt, None)
+        return {name: ((ms[i] * 1e3 / cnt[i]) if cnt[i] else 0.0, cnt[i] // n_iters) for i, name in enumerate(self.KERNEL_CLASSES)}
+
     def capture(self, batch: int = 1) -> None:
         _hip.call("pgk_engine_capture", self.handle, batch, None)
         self._captured_batch = batch
@@ -107,6 +116,15 @@ class Engine:
         _hip.call("pgk_engine_read_tokens", self.handle, out.ctypes.data_as(_hip.c_i32_p), batch, n_steps, None)
         return out
 
+    def shader_clock_mhz(self, n_steps: int) -> float:
+        """In-kernel shader clock over the last n_steps logged steps: d(s_memtime)/d(s_memrealtime) x 100 MHz."""
+        buf = np.zeros(2 * n_steps, np.uint64)
+        _hip.call("pgk_engine_read_clock", self.handle, buf.ctypes.data_as(C.POINTER(C.c_uint64)), n_steps, None)
+        t, r = buf[0::2].astype(np.float64), buf[1::2].astype(np.float64)
+        if n_steps < 2 or r[-1] == r[0]:
+            return 0.0
+        return float((t[-1] - t[0]) / (r[-1] - r[0]) * 100.0)
+
     def logits(self, batch: int = 1) -> GPUArray:
         """fp32 [batch, V] view of the last step's logits (owned by the engine)."""
         p = C.c_void_p()
@@ -123,6 +141,16 @@ class Engine:
         ka, va = GPUArray(shape, bfloat16, k.value, owns_memory=False), GPUArray(shape, bfloat16, v.value, owns_memory=False)
         ka._source_ref = va._source_ref = self
         return ka, va
+
+    def state_arrays(self, batch: int) -> tuple[GPUArray, GPUArray]:
+        """int32 [batch] views of the device-resident (token, position) state."""
+        from pygpukit_amd.core.dtypes import int32
+
+        t, p = C.c_void_p(), C.c_void_p()
+        _hip.call("pgk_engine_state_ptr", self.handle, C.byref(t), C.byref(p))
+        ta, pa = GPUArray((batch,), int32, t.value, owns_memory=False), GPUArray((batch,), int32, p.value, owns_memory=False)
+        ta._source_ref = pa._source_ref = self
+        return ta, pa
 
     def launches_per_step(self) -> int:
         n = C.c_int()

@@ -65,10 +65,10 @@ struct DecodeState {
 // Walk positions [c0, c1) of one KV head's cache rows (row stride D elements).
 // qf[g][8]: this lane's slice of the G pre-scaled queries.  Wave `wid` of 4 takes every 4th
 // position-group.  LPR = D/8 lanes per row.
-template <class T, int D, int G>
+template <class T, int D, int G, int NWV = 4>
 __device__ __forceinline__ void decode_walk(const T* kbase, const T* vbase, int c0, int c1, const float (&qf)[G][8],
                                             int lane, int wid, DecodeState<G>& st) {
-    constexpr int LPR = D / 8, PPW = 64 / LPR, U = 4, STRIDE = 4 * PPW;
+    constexpr int LPR = D / 8, PPW = 64 / LPR, U = 4, STRIDE = NWV * PPW;
     const int grp = lane / LPR, sub = lane % LPR;
     // U position-groups per trip: all 2*U 16-byte loads are issued before the first is consumed, so a
     // short chunk costs ONE memory round trip instead of one per position.
@@ -91,8 +91,7 @@ __device__ __forceinline__ void decode_walk(const T* kbase, const T* vbase, int 
                 float d = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) d = fmaf(qf[g][j], kf[u][j], d);
-#pragma unroll
-                for (int off = LPR / 2; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
+                d = group_sum<LPR>(d);
                 s[g] = d;
             }
             if (valid[u]) st.update(s, vf[u]);  // lane-group uniform
@@ -104,9 +103,9 @@ __device__ __forceinline__ void decode_walk(const T* kbase, const T* vbase, int 
 // `clamp_max`, so they can be issued before the context length is known), consume them later.
 template <int U> struct KVBatch { uint4 k[U], v[U]; };
 
-template <int D, int U>
+template <int D, int U, int NWV = 4>
 __device__ __forceinline__ void kv_issue(KVBatch<U>& kb, const bf16* kbase, const bf16* vbase, int p0, int clamp_max, int lane) {
-    constexpr int LPR = D / 8, PPW = 64 / LPR, STRIDE = 4 * PPW;
+    constexpr int LPR = D / 8, PPW = 64 / LPR, STRIDE = NWV * PPW;
     const int grp = lane / LPR, sub = lane % LPR;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -116,31 +115,55 @@ __device__ __forceinline__ void kv_issue(KVBatch<U>& kb, const bf16* kbase, cons
     }
 }
 
-template <int D, int G, int U>
+template <int D, int G, int U, int NWV = 4>
 __device__ __forceinline__ void kv_consume(const KVBatch<U>& kb, int p0, int c1, const float (&qf)[G][8], int lane,
                                            DecodeState<G>& st) {
-    constexpr int LPR = D / 8, PPW = 64 / LPR, STRIDE = 4 * PPW;
+    constexpr int LPR = D / 8, PPW = 64 / LPR, STRIDE = NWV * PPW;
     const int grp = lane / LPR;
+    // batch-wise softmax: all U scores first (independent dot products), ONE running-max update and one
+    // rescale per batch - a short dependency chain instead of U chained exp/rescale steps.
+    float s[U][G];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const bool valid = p0 + u * STRIDE + grp < c1;
-        Vec<bf16> kv, vv;
+        Vec<bf16> kv;
         kv.raw = kb.k[u];
-        vv.raw = kb.v[u];
-        float kf[8], vf[8];
+        float kf[8];
         kv.to_float(kf);
-        vv.to_float(vf);
-        float s[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float d = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) d = fmaf(qf[g][j], kf[j], d);
-#pragma unroll
-            for (int off = LPR / 2; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
-            s[g] = d;
+            d = group_sum<LPR>(d);
+            s[u][g] = valid ? d : -INFINITY;
         }
-        if (valid) st.update(s, vf);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float mx = st.m[g];
+#pragma unroll
+        for (int u = 0; u < U; ++u) mx = fmaxf(mx, s[u][g]);
+        if (mx == -INFINITY) continue;  // nothing valid yet for this lane-group
+        const float alpha = __expf(st.m[g] - mx);
+        float lsum = 0.f, acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = st.o[g][j] * alpha;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float pw = __expf(s[u][g] - mx);  // exp(-inf) = 0 for masked positions
+            lsum += pw;
+            Vec<bf16> vv;
+            vv.raw = kb.v[u];
+            float vf[8];
+            vv.to_float(vf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(pw, vf[j], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) st.o[g][j] = acc[j];
+        st.l[g] = st.l[g] * alpha + lsum;
+        st.m[g] = mx;
     }
 }
 
@@ -181,10 +204,10 @@ __device__ __forceinline__ void decode_block_merge(const DecodeState<G>& st, flo
 
 // Same merge, but the workgroup saw the WHOLE context: write the normalised attention output
 // attn[g*D + d] into LDS (`attn_out`, G*D floats) for a consumer inside the same kernel.
-template <int D, int G>
+template <int D, int G, int NWV = 4>
 __device__ __forceinline__ void decode_block_merge_lds(const DecodeState<G>& st, float* lds, float* attn_out, int lane,
                                                        int wid) {
-    constexpr int LPR = D / 8, PPW = 64 / LPR, NS = 4 * PPW, RS = D + 2;
+    constexpr int LPR = D / 8, PPW = 64 / LPR, NS = NWV * PPW, RS = D + 2;
     const int grp = lane / LPR, sub = lane % LPR;
     const int slot = wid * PPW + grp;
 #pragma unroll

@@ -462,8 +462,7 @@ __device__ __forceinline__ void prepare_new_token(const AttnArgs& a, int b, int 
             float ss = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) ss = fmaf(x[j], x[j], ss);
-#pragma unroll
-            for (int off = LPR / 2; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+            ss = group_sum<LPR>(ss);
             const float inv = 1.0f / sqrtf(ss / D + a.eps);
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = x[j] * inv * gamma[j];
@@ -471,7 +470,7 @@ __device__ __forceinline__ void prepare_new_token(const AttnArgs& a, int b, int 
         const bool lo = sub < LPR / 2;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float other = __shfl_xor(x[j], LPR / 2, 64);
+            const float other = xor_half<LPR>(x[j]);
             o[j] = lo ? (x[j] * csv[j] - other * snv[j]) : (x[j] * csv[j] + other * snv[j]);
         }
     };
@@ -503,8 +502,7 @@ __device__ __forceinline__ void fold_new_token(const NewToken<D, G>& t, DecodeSt
         float dsum = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) dsum = fmaf(t.qf[g][j], t.kn[j], dsum);
-#pragma unroll
-        for (int off = LPR / 2; off >= 1; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
+        dsum = group_sum<LPR>(dsum);
         s[g] = dsum;
     }
     st.update(s, t.vn);
@@ -537,16 +535,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
                              (size_t)a.nsplit * RS, lane, wid);
 }
 
-// fused path: grid (H / rows_per_block, Hkv, batch).  Every workgroup of a KV head recomputes that
-// head's (short-context) attention from L2-resident K/V, then multiplies it with ITS slice of W_o
+// fused path: grid (H / rows_per_block, Hkv, batch), 512 threads.  Every workgroup of a KV head recomputes
+// that head's (short-context) attention from L2-resident K/V, then multiplies it with ITS slice of W_o
 // (rows_per_block output rows x G*D columns), whose loads were issued before anything else.
 template <int D, int G>
 __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a) {
+    constexpr int NWV = 4;   // 8 waves measured slower: the kernel is issue-bound per SIMD, not per wave
     constexpr int LPR = D / 8, PPW = 64 / LPR, RS = D + 2;
     constexpr int GD = G * D, LPW = GD / 8;          // lanes covering one W_o row slice
-    constexpr int RPP = 256 / LPW;                   // rows per pass of the workgroup
+    constexpr int RPP = NWV * 64 / LPW;              // rows per pass of the workgroup
     constexpr int PRE = 4;                           // preloaded passes
-    __shared__ float lds[4 * PPW * G * RS];
+    constexpr int U0 = 12;                           // position-groups per wave in the first KV batch
+    __shared__ float lds[NWV * PPW * G * RS];
     __shared__ __attribute__((aligned(16))) float attn[GD];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane % LPR;
     const int kvh = blockIdx.y, b = blockIdx.z;
@@ -560,12 +560,11 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a) {
     for (int p = 0; p < PRE; ++p)  // unconditional (clamped) so nothing waits on these until the GEMV
         pre[p] = load_nt16(wbase + (size_t)(r0 + min(p, npass - 1) * RPP + rip) * ldw);
 
-    // first KV batch: 12 position-groups per wave = positions [0, 48*PPW); addresses do not depend on the
-    // context length (clamped), so these loads share the round trip of everything else in this kernel
-    constexpr int U0 = 12;
+    // first KV batch: U0 position-groups per wave = positions [0, U0*NWV*PPW); addresses do not depend on
+    // the context length (clamped), so these loads share the round trip of everything else in this kernel
     const size_t head_off = (((size_t)b * a.hkv + kvh) * a.max_seq) * D;
     KVBatch<U0> kb0;
-    kv_issue<D, U0>(kb0, a.kcache + head_off, a.vcache + head_off, wid * PPW, a.max_seq - 1, lane);
+    kv_issue<D, U0, NWV>(kb0, a.kcache + head_off, a.vcache + head_off, wid * PPW, a.max_seq - 1, lane);
     const int pos = a.positions[b];
     NewToken<D, G> t;
     prepare_new_token<D, G>(a, b, kvh, pos, lane, t);
@@ -576,11 +575,11 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a) {
     DecodeState<G> st;
     st.init();
     const int c1 = min(pos, a.max_seq);
-    kv_consume<D, G, U0>(kb0, wid * PPW, c1, t.qf, lane, st);
-    if (c1 > U0 * 4 * PPW)
-        decode_walk<bf16, D, G>(a.kcache + head_off, a.vcache + head_off, U0 * 4 * PPW, c1, t.qf, lane, wid, st);
+    kv_consume<D, G, U0, NWV>(kb0, wid * PPW, c1, t.qf, lane, st);
+    if (c1 > U0 * NWV * PPW)
+        decode_walk<bf16, D, G, NWV>(a.kcache + head_off, a.vcache + head_off, U0 * NWV * PPW, c1, t.qf, lane, wid, st);
     if (wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
-    decode_block_merge_lds<D, G>(st, lds, attn, lane, wid);
+    decode_block_merge_lds<D, G, NWV>(st, lds, attn, lane, wid);
 
     float xf[8];
     {
@@ -596,8 +595,7 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a) {
         float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc = fmaf(wf[j], xf[j], acc);
-#pragma unroll
-        for (int off = LPW / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        acc = group_sum<LPW>(acc);
         if (lr == 0) outp[row] = acc;
     }
 }
@@ -664,8 +662,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kvwrite_kernel(bf16* qkv, con
             float ss = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) ss = fmaf(x[j], x[j], ss);
-#pragma unroll
-            for (int off = LPR / 2; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+            ss = group_sum<LPR>(ss);
             const float inv = 1.0f / sqrtf(ss / D + eps);
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = x[j] * inv * to_f(gamma[sub * 8 + j]);
@@ -676,7 +673,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kvwrite_kernel(bf16* qkv, con
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float other = __shfl_xor(x[j], LPR / 2, 64);
+            const float other = xor_half<LPR>(x[j]);
             const int dd = (sub * 8 + j) % HALF;
             o[j] = lo ? (x[j] * cs[dd] - other * sn[dd]) : (x[j] * cs[dd] + other * sn[dd]);
         }
@@ -993,6 +990,7 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         const int gd = G * c.head_dim, rpp = 256 / (gd / 8);
         int rows = c.hidden_size / 32;
         while (rows > 4 * rpp && rows % 2 == 0) rows /= 2;   // <= 4 preloaded passes per workgroup
+        while (rows < rpp) rows *= 2;
         const bool tiles = rows % rpp == 0 && c.hidden_size % rows == 0 && gd / 8 <= 64;
         if (const char* dbg = getenv("PGK_DEBUG_SKIP")) e->skip_attn = atoi(dbg) & 16;  // timing ablation only
         const char* env = getenv("PGK_FUSED_ATTN");

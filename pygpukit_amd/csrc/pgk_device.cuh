@@ -84,26 +84,52 @@ template <> __device__ __forceinline__ void Vec<f16>::from_float(const float (&f
 }
 
 // ---- reductions ---------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, WAVE);
+// Cross-lane traffic goes through DPP (register-to-register, a few cycles) instead of ds_bpermute
+// (an LDS-pipe round trip per step): a decode kernel's critical path is a chain of these.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i within each 8
+constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15-i within each 16
+constexpr int DPP_ROR8 = 0x128;        // rotate by 8 within each 16 (== xor 8)
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// all-reduce over aligned groups of 8 / 16 lanes
+__device__ __forceinline__ float group8_sum(float v) {
+    v += dpp_f<DPP_XOR1>(v); v += dpp_f<DPP_XOR2>(v); v += dpp_f<DPP_HALF_MIRROR>(v);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
-    return v;
-}
-// Sum over the 16 lanes that share (lane >> 4).
 __device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    v = group8_sum(v);
+    v += dpp_f<DPP_MIRROR>(v);
     return v;
 }
 __device__ __forceinline__ float group16_max(float v) {
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v)); v = fmaxf(v, dpp_f<DPP_MIRROR>(v));
     return v;
+}
+template <int LANES> __device__ __forceinline__ float group_sum(float v) {  // LANES in {8,16,32,64}, aligned groups
+    if constexpr (LANES == 8) return group8_sum(v);
+    v = group16_sum(v);
+    if constexpr (LANES == 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (LANES == 64) v = readlane_f(v, 0) + readlane_f(v, 16) + readlane_f(v, 32) + readlane_f(v, 48);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+__device__ __forceinline__ float wave_max(float v) {
+    v = group16_max(v);
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+// value held by the lane LANES/2 away inside an aligned group of LANES (rotate-half partner)
+template <int LANES> __device__ __forceinline__ float xor_half(float v) {
+    if constexpr (LANES == 16) return dpp_f<DPP_ROR8>(v);
+    else return __shfl_xor(v, LANES / 2, 64);
 }
 
 // Block-wide sum for blocks of up to 1024 threads (16 waves); `scratch` holds >= 16 floats.

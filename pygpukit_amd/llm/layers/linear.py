@@ -93,8 +93,14 @@ class LinearFP8:
 
 
 def quantize_linear_fp8(weight_f32: np.ndarray) -> tuple[GPUArray, GPUArray]:
+    """Device arrays for quantize_fp8_host(weight): (codes uint8 [out,in], scale bf16 [out/128,in/128])."""
+    codes, sbits = quantize_fp8_host(weight_f32)
+    return from_numpy(codes), from_numpy(sbits)
+
+
+def quantize_fp8_host(weight_f32: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
     """Host helper for synthetic/benchmark weights: per-128x128-block absmax/448 scale (rounded to bf16),
-    nearest-even E4M3 codes, never 0x7F/0xFF.  Returns (codes uint8 [out,in], scale bf16 [out/128,in/128])."""
+    nearest-even E4M3 codes, never 0x7F/0xFF.  Returns (codes uint8 [out,in], scale bf16-bits [out/128,in/128])."""
     H, W = weight_f32.shape
     blocks = weight_f32.reshape(H // 128, 128, W // 128, 128).astype(np.float32)
     absmax = np.abs(blocks).max(axis=(1, 3))
@@ -111,7 +117,7 @@ def quantize_linear_fp8(weight_f32: np.ndarray) -> tuple[GPUArray, GPUArray]:
     pick_lo = np.where(dlo == dhi, (lo % 2) == 0, dlo < dhi)
     code = np.where(pick_lo, lo, hi).astype(np.uint8)
     code = np.where((x < 0) & (code != 0), code | 0x80, code).astype(np.uint8)
-    return from_numpy(code.reshape(H, W)), from_numpy(sbits)
+    return code.reshape(H, W), sbits
 
 
-__all__ = ["LinearBF16", "LinearFP8", "Linear", "quantize_linear_fp8"]
+__all__ = ["LinearBF16", "LinearFP8", "Linear", "quantize_linear_fp8", "quantize_fp8_host"]

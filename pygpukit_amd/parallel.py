@@ -128,3 +128,34 @@ class RcclComm:
         if self._h:
             self._hip.call("pgk_comm_destroy", C.c_void_p(self._h))
             self._h = 0
+
+
+class DataParallelDecoder:
+    """Greedy batch decode of independent sequences sharded over the ranks (BASELINE config 4).
+
+    `runner(prompts) -> int32 [n_steps, len(prompts)]` decodes one rank's shard (on the GPU path:
+    DecodeBatch.prefill + run_greedy on the native engine).  Shards are contiguous blocks of the global
+    batch (shard_range); the data path has no collective; tokens are gathered once at the end (or per step
+    by the caller) over `gather`, which defaults to the control plane and is RCCL on the GPU path."""
+
+    def __init__(self, cp: ControlPlane, runner, gather=None):
+        self.cp, self.runner, self._gather = cp, runner, gather
+
+    def decode(self, prompts: list[list[int]], n_steps: int) -> np.ndarray | None:
+        """Every rank passes the SAME global prompt list; returns int32 [n_steps, len(prompts)] on every rank."""
+        n = len(prompts)
+        lo, hi = shard_range(n, self.cp.rank, self.cp.world)
+        local = self.runner(prompts[lo:hi], n_steps) if hi > lo else np.zeros((n_steps, 0), np.int32)
+        local = np.ascontiguousarray(local, dtype=np.int32)
+        if local.shape != (n_steps, hi - lo):
+            raise ValueError(f"runner returned {local.shape}, expected {(n_steps, hi - lo)}")
+        # equal-length payloads for the all-gather: pad every shard to the largest shard
+        width = -(-n // self.cp.world)
+        padded = np.full((n_steps, width), -1, np.int32)
+        padded[:, : hi - lo] = local
+        gathered = (self._gather or self.cp.gather_int32)(padded.ravel())  # [world, n_steps*width]
+        out = np.empty((n_steps, n), np.int32)
+        for r in range(self.cp.world):
+            rlo, rhi = shard_range(n, r, self.cp.world)
+            out[:, rlo:rhi] = np.asarray(gathered[r]).reshape(n_steps, width)[:, : rhi - rlo]
+        return out

@@ -218,10 +218,19 @@ def main() -> None:
     ab = algorithmic_bytes_per_token(cfg, ctx_mid, args.weight_format)
     lm_us = prof["lmhead"][0]
     lm_bytes = ab["lm_head"] + cfg["hidden_size"] * 4 * B + cfg["vocab_size"] * 4 * B
+    traffic = None
+    try:  # HBM bytes per launch from the committed rocprofv3 --pmc pass (FETCH_SIZE x2 per the microarch guide + WRITE_SIZE)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_decode_pmc_hbm.json")))
+        for k, v in pmc.items():
+            if "1, 4, 0, 3, 2" in k:  # <bf16, float, M=1, R=4, PRO_NORM, EPI_LOGITS, C=2>
+                traffic = v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"]
+    except Exception:
+        pass
     roofline = {"kernel": "fused_gemv_kernel<bf16, PRO_NORM, EPI_LOGITS> (lm_head + argmax partials)", "bound": "hbm",
                 "achieved": lm_bytes / lm_us / 1e3 if lm_us else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (lm_bytes / lm_us / 1e3 / HBM_PEAK_GBS) if lm_us else None, "traffic": None,
-                "bytes_per_launch": lm_bytes, "us_per_launch": lm_us, "timing": "hipEvent pair around each eager launch, 8 steps"}
+                "frac": (lm_bytes / lm_us / 1e3 / HBM_PEAK_GBS) if lm_us else None,
+                "traffic": traffic if (B == 1 and args.weight_format == "bf16") else None,
+                "bytes_per_launch": lm_bytes, "us_per_launch": lm_us, "timing": "hipEvent pair around each eager launch minus the measured empty event-pair cost, 8 steps"}
     step_ms = dev_ms_max / K
     step_bytes = ab["weights"] + ab["lm_head"] + B * (ab["kv_read"] + ab["kv_write"] + ab["logits"])
     step_roofline = {"bound": "hbm", "achieved": step_bytes / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1202,17 +1202,22 @@ pgk_status pgk_engine_profile_step(pgk_engine eh, int batch, int n_iters, float*
     for (int it = 0; it < n_iters && r == PGK_OK; ++it) {
         timer.used = 0;
         g_timer = &timer;
+        mark(-1, st);   // calibration: two events with nothing between them measure the event's own cost,
+        mark(-2, st);   // which is subtracted from every event-to-event interval below
         int launches = 0;
         r = decode_step(e, batch, st, &launches);
         g_timer = nullptr;
         if (r != PGK_OK) break;
         hipError_t he = hipStreamSynchronize(st);
         if (he != hipSuccess) { r = set_error(PGK_ERR_HIP, "pgk_engine_profile_step: %s", hipGetErrorString(he)); break; }
+        float overhead = 0.f;
+        (void)hipEventElapsedTime(&overhead, timer.ev[0], timer.ev[1]);
         for (size_t i = 1; i < timer.used; ++i) {
-            if (timer.cls[i] < 0) continue;  // origin marker of the next chunk
+            if (timer.cls[i] < 0) continue;  // origin / calibration markers
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, timer.ev[i - 1], timer.ev[i]) == hipSuccess) {
-                h_ms_sum[timer.cls[i]] += ms;
+                ms -= overhead;
+                h_ms_sum[timer.cls[i]] += ms > 0.f ? ms : 0.f;
                 h_count[timer.cls[i]] += 1;
             }
         }

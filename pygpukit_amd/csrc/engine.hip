@@ -239,6 +239,16 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a) {
 #pragma unroll
             for (int c = 0; c < (C > 0 ? C : 1); ++c) {
                 const int k0 = lane * NW + c * 64 * NW;
+                if constexpr (std::is_same<WT, bf16>::value && std::is_same<XT, bf16>::value) {
+                    uint4 xr[M];
+#pragma unroll
+                    for (int m = 0; m < M; ++m) xr[m] = *reinterpret_cast<const uint4*>(xs + (size_t)m * K + k0);
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int m = 0; m < M; ++m) acc[r][m] = dot8_bf16(pre[r][c], xr[m], acc[r][m]);
+                    continue;
+                }
                 float xf[M][NW];
 #pragma unroll
                 for (int m = 0; m < M; ++m) XLoad<XT, NW>::load(xs + (size_t)m * K + k0, xf[m]);
@@ -535,7 +545,42 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
                              (size_t)a.nsplit * RS, lane, wid);
 }
 
-// fused path: grid (H / rows_per_block, Hkv, batch), 512 threads.  Every workgroup of a KV head recomputes
+// split path, step 2: merge the nsplit (<= 64) chunk records of every head into the normalised attention
+// vector attn[b][h*D + d] (fp32).  grid (Hq, batch), D threads (D = 64 or 128: whole waves).  Lane s of wave 0
+// owns record s's (m, l): one load each, a wave max and a wave sum give the weights; then every thread sums its
+// element over the records with independent loads.
+template <int D>
+__global__ void attn_merge_kernel(const float* part, float* attn, int hq, int nsplit) {
+    __shared__ float w_s[64];
+    __shared__ float inv_l;
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    const float* recs = part + ((size_t)b * hq + h) * nsplit * (D + 2);
+    if (threadIdx.x < 64) {
+        const int s = threadIdx.x;
+        const int sc = min(s, nsplit - 1);
+        float m = recs[(size_t)sc * (D + 2)], l = recs[(size_t)sc * (D + 2) + 1];
+        if (s >= nsplit) { m = -INFINITY; l = 0.f; }
+        const float mx = wave_max(m);
+        const float w = (m == -INFINITY) ? 0.f : __expf(m - mx);
+        const float tot = wave_sum(w * l);
+        w_s[s] = w;
+        if (s == 0) inv_l = tot > 0.f ? 1.0f / tot : 0.f;
+    }
+    __syncthreads();
+    float o = 0.f;
+    int s = 0;
+    for (; s + 8 <= nsplit; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = recs[(size_t)(s + u) * (D + 2) + 2 + d];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o = fmaf(w_s[s + u], v[u], o);
+    }
+    for (; s < nsplit; ++s) o = fmaf(w_s[s], recs[(size_t)s * (D + 2) + 2 + d], o);
+    attn[((size_t)b * hq + h) * D + d] = o * inv_l;
+}
+
+// fused path: grid (H / rows_per_block, Hkv, batch), 256 threads.  Every workgroup of a KV head recomputes
 // that head's (short-context) attention from L2-resident K/V, then multiplies it with ITS slice of W_o
 // (rows_per_block output rows x G*D columns), whose loads were issued before anything else.
 template <int D, int G>
@@ -753,7 +798,7 @@ struct Engine {
     bf16 *kcache = nullptr, *vcache = nullptr;
     float *rope_cos = nullptr, *rope_sin = nullptr, *cur_cos = nullptr, *cur_sin = nullptr;
     int32_t *tokens = nullptr, *positions = nullptr, *token_log = nullptr, *step_counter = nullptr;
-    float *h = nullptr, *h2 = nullptr, *qkv = nullptr, *part = nullptr, *opart = nullptr, *act = nullptr, *logits = nullptr,
+    float *h = nullptr, *h2 = nullptr, *qkv = nullptr, *part = nullptr, *opart = nullptr, *attnv = nullptr, *act = nullptr, *logits = nullptr,
           *amax_val = nullptr;
     int* amax_idx = nullptr;
     unsigned long long* clk_log = nullptr;
@@ -805,7 +850,7 @@ template <class WT, class XT, int M, int R, int PRO, int EPI>
 static pgk_status launch_fused(const FusedArgs& a, int n_out, hipStream_t st, int force_grid = 0) {
     constexpr int NW = WTraits<WT>::NW;
     const int c = (a.K % (64 * NW) == 0) ? a.K / (64 * NW) : 0;
-    constexpr int BUDGET = (M > 4 ? 4 : 8) / R;  // R*C*4 preload VGPRs: <= 32 (16 at large M)
+    constexpr int BUDGET = 8 / R;  // R*C*4 preload VGPRs <= 32
     if constexpr (1 <= BUDGET) { if (c == 1) return launch_fused_c<WT, XT, M, R, PRO, EPI, 1>(a, n_out, st, force_grid); }
     if constexpr (2 <= BUDGET) { if (c == 2) return launch_fused_c<WT, XT, M, R, PRO, EPI, 2>(a, n_out, st, force_grid); }
     if constexpr (3 <= BUDGET) { if (c == 3) return launch_fused_c<WT, XT, M, R, PRO, EPI, 3>(a, n_out, st, force_grid); }
@@ -828,7 +873,7 @@ static pgk_status launch_fused_auto(const FusedArgs& a, int n_out, hipStream_t s
 }
 
 template <int D>
-static pgk_status launch_attn(Engine* e, int layer, int b0, int m, hipStream_t st) {
+static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, hipStream_t st) {
     const auto& c = e->cfg;
     const auto& L = e->layers[layer];
     const int G = c.num_heads / c.num_kv_heads;
@@ -848,10 +893,10 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, hipStream_t s
     a.nsplit = e->nsplit;
     a.w_o = (const bf16*)L.w_o; a.H = c.hidden_size; a.rows_per_block = e->oproj_rows;
     a.opart = e->opart ? e->opart + (size_t)b0 * c.num_kv_heads * c.hidden_size : nullptr;
-    dim3 grid = e->fused_attn ? dim3(c.hidden_size / e->oproj_rows, c.num_kv_heads, m) : dim3(e->nsplit, c.num_kv_heads, m);
+    dim3 grid = fused ? dim3(c.hidden_size / e->oproj_rows, c.num_kv_heads, m) : dim3(e->nsplit, c.num_kv_heads, m);
 #define PGK_ATTN(GG)                                                               \
     case GG:                                                                       \
-        if (e->fused_attn) attn_oproj_kernel<D, GG><<<grid, 256, 0, st>>>(a);      \
+        if (fused) attn_oproj_kernel<D, GG><<<grid, 256, 0, st>>>(a);              \
         else attn_decode_kernel<D, GG><<<grid, 256, 0, st>>>(a);                   \
         break;
     switch (G) {
@@ -859,6 +904,9 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, hipStream_t s
         default: return set_error(PGK_ERR_UNSUPPORTED, "engine: GQA group %d not in {1,2,4}", G);
     }
 #undef PGK_ATTN
+    if (!fused) {
+        attn_merge_kernel<D><<<dim3(c.num_heads, m), D, 0, st>>>(a.part, e->attnv + (size_t)b0 * c.num_heads * D, c.num_heads, e->nsplit);
+    }
     PGK_CHECK_HIP(hipGetLastError());
     return PGK_OK;
 }
@@ -870,6 +918,9 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
     const int H = c.hidden_size, I = c.intermediate_size, D = c.head_dim, QD = c.num_heads * D, NQKV = e->qkv_dim();
     float* h = e->h + (size_t)b0 * H;
     float* h2 = e->h2 + (size_t)b0 * H;
+    // fused attention+o_proj recomputes a KV head's attention in every row-slice workgroup: right for one or
+    // two sequences at short context, wasteful for a batch - batches take the split-KV path.
+    const bool fused = e->fused_attn && M <= 2;
     mark(-1, st);  // time origin
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& L = e->layers[l];
@@ -882,31 +933,36 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
         mark(KC_NORM_QKV, st);
         // 2. attention (QK-norm, RoPE, KV write fused; on the fused path also the o_proj partial products)
         if (!e->skip_attn) {
-            if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, st)) return r; }
-            else { if (pgk_status r = launch_attn<64>(e, l, b0, M, st)) return r; }
+            if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, fused, st)) return r; }
+            else { if (pgk_status r = launch_attn<64>(e, l, b0, M, fused, st)) return r; }
         }
         mark(KC_ATTN, st);
         const float* mlp_in = h;
-        if (!e->fused_attn) {
-            // 3. h += Wo . attn
+        if (!fused) {
+            // 3. h += Wo . attn   (attn = merged split-KV records, written by attn_merge_kernel)
             a = FusedArgs{};
-                a.w = L.w_o; a.wscale = (const bf16*)L.s_o; a.N = H; a.K = QD;
-            a.part = e->part + (size_t)b0 * c.num_heads * e->nsplit * (D + 2); a.nsplit = e->nsplit; a.hq = c.num_heads; a.d = D;
+            a.w = L.w_o; a.wscale = (const bf16*)L.s_o; a.N = H; a.K = QD;
+            a.xin = e->attnv + (size_t)b0 * QD;
             a.res = h; a.out = h; a.ld_out = H;
-            if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_ATTN, EPI_RESID>(a, H, st)) return r;
+            if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_PLAIN, EPI_RESID>(a, H, st)) return r;
             mark(KC_OPROJ, st);
-            ++*launches;
+            *launches += 2;
         }
         // 4. act = silu(Wg x) * (Wu x), x = rmsnorm(h [+ sum of o_proj partials])
         a = FusedArgs{};
         a.w = L.w_gate_up; a.wscale = (const bf16*)L.s_gate_up; a.N = I; a.K = H;
         a.h = h; a.gamma = (const bf16*)L.mlp_norm; a.eps = c.norm_eps;
         a.out = e->act + (size_t)b0 * I; a.ld_out = I;
-        if (e->fused_attn) {
-            a.part = e->opart + (size_t)b0 * c.num_kv_heads * H; a.nsplit = c.num_kv_heads; a.h_out = h2;
-            if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM_SUM, EPI_SWIGLU>(a, I, st)) return r;
-            mlp_in = h2;
-        } else {
+        bool done_gateup = false;
+        if constexpr (M <= 2) {   // the fused path only ever runs for one or two sequences per chunk
+            if (fused) {
+                a.part = e->opart + (size_t)b0 * c.num_kv_heads * H; a.nsplit = c.num_kv_heads; a.h_out = h2;
+                if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM_SUM, EPI_SWIGLU>(a, I, st)) return r;
+                mlp_in = h2;
+                done_gateup = true;
+            }
+        }
+        if (!done_gateup) {
             if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM, EPI_SWIGLU>(a, I, st)) return r;
         }
         mark(KC_GATEUP, st);
@@ -982,8 +1038,8 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
     e->lm_head = (const bf16*)(lm_head ? lm_head : embed);
     e->final_norm = (const bf16*)final_norm;
     e->layers.assign(layers, layers + c.num_layers);
-    int nsplit = (c.max_seq_len + 127) / 128;
-    e->nsplit = nsplit < 1 ? 1 : (nsplit > 32 ? 32 : nsplit);
+    int nsplit = (c.max_seq_len + 63) / 64;   // ~64 cached positions per workgroup: one KV batch per wave
+    e->nsplit = nsplit < 1 ? 1 : (nsplit > 64 ? 64 : nsplit);
     e->lm_blocks = 1024;
     // fused attention + o_proj: short contexts, bf16 W_o, and a row slicing that tiles the workgroup
     {
@@ -1017,6 +1073,7 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
     A((void**)&e->qkv, (size_t)B * e->qkv_dim() * 4, &e->ws_bytes);
     A((void**)&e->part, (size_t)B * c.num_heads * e->nsplit * (D + 2) * 4, &e->ws_bytes);
     A((void**)&e->opart, (size_t)B * c.num_kv_heads * H * 4, &e->ws_bytes);
+    A((void**)&e->attnv, (size_t)B * c.num_heads * D * 4, &e->ws_bytes);
     A((void**)&e->act, (size_t)B * c.intermediate_size * 4, &e->ws_bytes);
     A((void**)&e->logits, (size_t)B * c.vocab_size * 4, &e->ws_bytes);
     A((void**)&e->amax_val, (size_t)B * e->lm_blocks * 4, &e->ws_bytes);

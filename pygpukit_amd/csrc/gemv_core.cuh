@@ -15,6 +15,8 @@
 // 64-lane waves, not a transliteration.
 #pragma once
 
+#include <type_traits>
+
 #include "pgk_device.cuh"
 
 namespace pgk {
@@ -116,6 +118,18 @@ template <int NW> struct XLoad<f16, NW> {
     }
 };
 
+// bf16 x bf16: v_dot2c_f32_bf16 consumes two packed pairs per instruction (products exact in fp32, fp32
+// accumulate) - 4 instructions per 16-byte chunk instead of 8 unpacks + 8 FMAs; this is what keeps the
+// M >= 4 batched GEMV from going VALU-bound.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot8_bf16(const uint4& w, const uint4& x, float acc) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.x), __builtin_bit_cast(bf16x2_t, x.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.y), __builtin_bit_cast(bf16x2_t, x.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.z), __builtin_bit_cast(bf16x2_t, x.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.w), __builtin_bit_cast(bf16x2_t, x.w), acc, false);
+    return acc;
+}
+
 // Partial dot products of R weight rows against M activation rows over the K range this lane
 // owns (k = lane*NW + i*64*NW).  wrow[r] points at row r's first element; xs is x[M][ldx] in LDS.
 // Results are per-lane partials: the caller reduces across the wave.
@@ -123,6 +137,21 @@ template <class WT, class XT, int M, int R>
 __device__ __forceinline__ void gemv_rows(const WT* const (&wrow)[R], const XT* xs, int ldx, int K, int lane,
                                           float (&acc)[R][M]) {
     constexpr int NW = WTraits<WT>::NW;
+    if constexpr (std::is_same<WT, bf16>::value && std::is_same<XT, bf16>::value) {
+#pragma unroll 2
+        for (int k0 = lane * 8; k0 < K; k0 += 64 * 8) {
+            uint4 raw[R], xr[M];
+#pragma unroll
+            for (int r = 0; r < R; ++r) raw[r] = load_nt16(wrow[r] + k0);
+#pragma unroll
+            for (int m = 0; m < M; ++m) xr[m] = *reinterpret_cast<const uint4*>(xs + (size_t)m * ldx + k0);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int m = 0; m < M; ++m) acc[r][m] = dot8_bf16(raw[r], xr[m], acc[r][m]);
+        }
+        return;
+    }
 #pragma unroll 2
     for (int k0 = lane * NW; k0 < K; k0 += 64 * NW) {
         uint4 raw[R];

@@ -34,6 +34,9 @@ namespace pgk {
 
 pgk_status engine_gemm_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, void* C, bool accum_f32, int M,
                           int N, int K, hipStream_t st);
+int wsgemm_pick_splits(int N, int K, bool allow_split);
+pgk_status wsgemm_nt(const bf16* a, int lda, const void* w, const bf16* wscale, bool fp8, void* c, const bf16* bias, int mode,
+                     int splits, int M, int N, int K, hipStream_t st);
 
 // --------------------------------------------------------------------------------------------
 // Fused GEMV kernel: prologue builds x[M][K] in LDS, body streams W, epilogue consumes y.
@@ -654,29 +657,53 @@ __global__ void embed_rows_kernel(const bf16* embed, const int32_t* tokens, floa
     for (int i = threadIdx.x; i < H; i += blockDim.x) h[(size_t)s * H + i] = to_f(row[i]);
 }
 
-// x_bf16[s] = rmsnorm(h32[s]) * gamma ; one wave per row
-__global__ __launch_bounds__(256) void rmsnorm_f32_bf16_kernel(const float* h, const bf16* gamma, bf16* out, int rows,
-                                                               int H, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* hr = h + (size_t)row * H;
+// h32[s] += sum of the split-K slabs of the projection that precedes this norm (if any), written back;
+// x_bf16[s] = rmsnorm(h32[s]) * gamma.  One 256-thread workgroup per row, 4 elements per thread per trip;
+// the slab loads are unconditional (clamped slab index, masked add) so they share one memory round trip.
+__global__ __launch_bounds__(256) void rmsnorm_f32_bf16_kernel(float* h, const bf16* gamma, bf16* out, int rows, int H,
+                                                               float eps, const float* slabs, int nslabs) {
+    __shared__ float red[16];
+    const int row = blockIdx.x;
+    float* hr = h + (size_t)row * H;
+    constexpr int MAXT = 4;                     // H <= 4096 handled in registers
+    float4 v[MAXT];
     float ss = 0.f;
-    for (int i = lane * 4; i < H; i += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(hr + i);
-        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int i = (threadIdx.x + t * 256) * 4;
+        if (i < H) {                            // block-uniform per t when H % 1024 == 0; otherwise per-lane tail
+            float4 acc = *reinterpret_cast<const float4*>(hr + i);
+            if (nslabs > 0) {
+                float4 p[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    p[s] = *reinterpret_cast<const float4*>(slabs + ((size_t)min(s, nslabs - 1) * rows + row) * H + i);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float w = s < nslabs ? 1.f : 0.f;
+                    acc.x = fmaf(w, p[s].x, acc.x); acc.y = fmaf(w, p[s].y, acc.y);
+                    acc.z = fmaf(w, p[s].z, acc.z); acc.w = fmaf(w, p[s].w, acc.w);
+                }
+                *reinterpret_cast<float4*>(hr + i) = acc;
+            }
+            v[t] = acc;
+            ss += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+        }
     }
-    ss = wave_sum(ss);
+    ss = block_sum(ss, red);
     const float inv = 1.0f / sqrtf(ss / H + eps);
-    for (int i = lane * 4; i < H; i += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(hr + i);
-        const uint2 g = *reinterpret_cast<const uint2*>(gamma + i);
-        const float g0 = __uint_as_float(g.x << 16), g1 = __uint_as_float(g.x & 0xFFFF0000u);
-        const float g2 = __uint_as_float(g.y << 16), g3 = __uint_as_float(g.y & 0xFFFF0000u);
-        uint2 o;
-        o.x = pack_bf16x2(v.x * inv * g0, v.y * inv * g1);
-        o.y = pack_bf16x2(v.z * inv * g2, v.w * inv * g3);
-        *reinterpret_cast<uint2*>(out + (size_t)row * H + i) = o;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int i = (threadIdx.x + t * 256) * 4;
+        if (i < H) {
+            const uint2 g = *reinterpret_cast<const uint2*>(gamma + i);
+            const float g0 = __uint_as_float(g.x << 16), g1 = __uint_as_float(g.x & 0xFFFF0000u);
+            const float g2 = __uint_as_float(g.y << 16), g3 = __uint_as_float(g.y & 0xFFFF0000u);
+            uint2 o;
+            o.x = pack_bf16x2(v[t].x * inv * g0, v[t].y * inv * g1);
+            o.y = pack_bf16x2(v[t].z * inv * g2, v[t].w * inv * g3);
+            *reinterpret_cast<uint2*>(out + (size_t)row * H + i) = o;
+        }
     }
 }
 
@@ -1140,7 +1167,12 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     hipStream_t st = resolve_stream(s);
     const int H = c.hidden_size, I = c.intermediate_size, D = c.head_dim, QD = c.num_heads * D, NQKV = e->qkv_dim();
     // workspace: h32 [n,H] f32 | x [n,H] | qkv [n,NQKV] | attn [n,QD] | gu [n,2I] | act [n,I]  (bf16)
-    const size_t need = (size_t)n * H * 4 + ((size_t)n * H + (size_t)n * NQKV + (size_t)n * QD + (size_t)n * 2 * I + (size_t)n * I) * 2 + 256;
+    // + split-K slabs of the N = hidden projections on the weight-streaming path (n <= 128)
+    const bool ws = n <= 128;
+    const int s_o = ws ? wsgemm_pick_splits(H, QD, true) : 1, s_d = ws ? wsgemm_pick_splits(H, I, true) : 1;
+    const size_t slab_elems = (size_t)(s_o > s_d ? s_o : s_d) * n * H;
+    const size_t need = (size_t)n * H * 4 + ((size_t)n * H + (size_t)n * NQKV + (size_t)n * QD + (size_t)n * 2 * I + (size_t)n * I) * 2 +
+                        (ws ? slab_elems * 4 : 0) + 512;
     if (need > e->pf_bytes) {
         if (e->pf) PGK_CHECK_HIP(hipStreamSynchronize(st));
         if (e->pf) pgk_free(e->pf);
@@ -1157,14 +1189,32 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
         PGK_REQUIRE(h_tokens[i] >= 0 && h_tokens[i] < c.vocab_size, "pgk_engine_prefill: token %d out of range", h_tokens[i]);
     PGK_CHECK_HIP(hipMemcpyAsync(e->pf_tokens, h_tokens, (size_t)n * 4, hipMemcpyHostToDevice, st));
     PGK_CHECK_HIP(hipStreamSynchronize(st));  // h_tokens may be pageable: make the copy complete before returning control
+    const bool fp8 = c.weight_format == 1;
     char* p = (char*)e->pf;
     float* h32 = (float*)p; p += (size_t)n * H * 4;
     bf16* x = (bf16*)p; p += (size_t)n * H * 2;
     bf16* qkv = (bf16*)p; p += (size_t)n * NQKV * 2;
     bf16* attn = (bf16*)p; p += (size_t)n * QD * 2;
     bf16* gu = (bf16*)p; p += (size_t)n * 2 * I * 2;
-    bf16* act = (bf16*)p;
-    const bool fp8 = c.weight_format == 1;
+    bf16* act = (bf16*)p; p += (size_t)n * I * 2;
+    float* slabs = (float*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    int pending = 0;   // split-K slabs of the previous projection still to be added into h32 by the next norm
+    auto proj_accum = [&](const bf16* x_in, const void* w, const void* sc, int N_, int K_, int splits) -> pgk_status {
+        if (!ws) return engine_gemm_nt(x_in, w, (const bf16*)sc, fp8, h32, true, n, N_, K_, st);
+        if (splits == 1) return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, h32, nullptr, 2, 1, n, N_, K_, st);
+        pending = splits;
+        return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, slabs, nullptr, 1, splits, n, N_, K_, st);
+    };
+    auto proj_store = [&](const bf16* x_in, const void* w, const void* sc, bf16* out_, int N_, int K_) -> pgk_status {
+        if (!ws) return engine_gemm_nt(x_in, w, (const bf16*)sc, fp8, out_, false, n, N_, K_, st);
+        return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, out_, nullptr, 0, 1, n, N_, K_, st);
+    };
+    auto norm = [&](const bf16* gamma) -> pgk_status {
+        rmsnorm_f32_bf16_kernel<<<n, 256, 0, st>>>(h32, gamma, x, n, H, c.norm_eps, slabs, pending);
+        pending = 0;
+        PGK_LAUNCH_CHECK();
+        return PGK_OK;
+    };
     embed_rows_kernel<<<n, 256, 0, st>>>(e->embed, e->pf_tokens, h32, H);
     PGK_LAUNCH_CHECK();
     const int kv_len = start_pos + n;
@@ -1172,9 +1222,8 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
         const auto& L = e->layers[l];
         bf16* kc = e->kcache + (size_t)l * e->kv_layer_elems() + (size_t)seq * c.num_kv_heads * c.max_seq_len * D;
         bf16* vc = e->vcache + (size_t)l * e->kv_layer_elems() + (size_t)seq * c.num_kv_heads * c.max_seq_len * D;
-        rmsnorm_f32_bf16_kernel<<<ceil_div(n, 4), 256, 0, st>>>(h32, (const bf16*)L.attn_norm, x, n, H, c.norm_eps);
-        PGK_LAUNCH_CHECK();
-        if (pgk_status r = engine_gemm_nt(x, L.w_qkv, (const bf16*)L.s_qkv, fp8, qkv, false, n, NQKV, H, st)) return r;
+        if (pgk_status r = norm((const bf16*)L.attn_norm)) return r;
+        if (pgk_status r = proj_store(x, L.w_qkv, L.s_qkv, qkv, NQKV, H)) return r;
         {
             const int nslots = c.num_heads + 2 * c.num_kv_heads;
             const bf16* qg = c.use_qk_norm ? (const bf16*)L.q_norm : nullptr;
@@ -1190,16 +1239,14 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
         if (pgk_status r = pgk_sdpa_causal(qkv, kc, vc, attn, c.num_heads, c.num_kv_heads, n, kv_len, D, 0.f, D, NQKV,
                                            (int64_t)c.max_seq_len * D, D, D, QD, PGK_BF16, st))
             return r;
-        if (pgk_status r = engine_gemm_nt(attn, L.w_o, (const bf16*)L.s_o, fp8, h32, true, n, H, QD, st)) return r;
-        rmsnorm_f32_bf16_kernel<<<ceil_div(n, 4), 256, 0, st>>>(h32, (const bf16*)L.mlp_norm, x, n, H, c.norm_eps);
-        PGK_LAUNCH_CHECK();
-        if (pgk_status r = engine_gemm_nt(x, L.w_gate_up, (const bf16*)L.s_gate_up, fp8, gu, false, n, 2 * I, H, st)) return r;
+        if (pgk_status r = proj_accum(attn, L.w_o, L.s_o, H, QD, s_o)) return r;
+        if (pgk_status r = norm((const bf16*)L.mlp_norm)) return r;
+        if (pgk_status r = proj_store(x, L.w_gate_up, L.s_gate_up, gu, 2 * I, H)) return r;
         swiglu_rows_kernel<<<ceil_div((long long)n * I / 8, 256) > 2048 ? 2048 : ceil_div((long long)n * I / 8, 256), 256, 0, st>>>(gu, act, n, I);
         PGK_LAUNCH_CHECK();
-        if (pgk_status r = engine_gemm_nt(act, L.w_down, (const bf16*)L.s_down, fp8, h32, true, n, H, I, st)) return r;
+        if (pgk_status r = proj_accum(act, L.w_down, L.s_down, H, I, s_d)) return r;
     }
-    rmsnorm_f32_bf16_kernel<<<ceil_div(n, 4), 256, 0, st>>>(h32, e->final_norm, x, n, H, c.norm_eps);
-    PGK_LAUNCH_CHECK();
+    if (pgk_status r = norm(e->final_norm)) return r;
     if (all_logits) {
         if (pgk_status r = engine_gemm_nt(x, e->lm_head, nullptr, false, all_logits, false, n, c.vocab_size, H, st)) return r;
     }

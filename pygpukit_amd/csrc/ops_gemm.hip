@@ -17,6 +17,8 @@
 namespace pgk {
 
 template <class T> pgk_status launch_gemv(const T*, const T*, const T*, T*, int, int, int, hipStream_t);
+pgk_status wsgemm_nt(const bf16* a, int lda, const void* w, const bf16* wscale, bool fp8, void* c, const bf16* bias, int mode,
+                     int splits, int M, int N, int K, hipStream_t st);
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -374,6 +376,8 @@ pgk_status pgk_gemm_nt(const void* a, const void* w, const void* bias, void* c, 
         if (dt == PGK_BF16) return launch_gemv<bf16>((const bf16*)a, (const bf16*)w, (const bf16*)bias, (bf16*)c, m, k, n, st);
         return launch_gemv<f16>((const f16*)a, (const f16*)w, (const f16*)bias, (f16*)c, m, k, n, st);
     }
+    if (dt == PGK_BF16 && m <= 128)   // weight-bound regime: stream W once through the skinny MFMA kernel
+        return wsgemm_nt((const bf16*)a, k, w, nullptr, false, c, (const bf16*)bias, 0, 1, m, n, k, st);
     if (dt == PGK_BF16) return dispatch_mfma<bf16, B_NT>((const bf16*)a, w, nullptr, (const bf16*)bias, (bf16*)c, m, n, k, st);
     return dispatch_mfma<f16, B_NT>((const f16*)a, w, nullptr, (const f16*)bias, (f16*)c, m, n, k, st);
 }
@@ -401,6 +405,7 @@ pgk_status pgk_w8a16_gemm_nk(const void* a, const uint8_t* w_nk, const void* sca
     PGK_REQUIRE(k % 128 == 0 && n % 128 == 0, "pgk_w8a16_gemm_nk: K=%d, N=%d must be multiples of the 128x128 scale block", k, n);
     PGK_REQUIRE(aligned16(a) && aligned16(w_nk), "pgk_w8a16_gemm_nk: operands must be 16-byte aligned");
     if (!m) return PGK_OK;
+    if (m <= 128) return wsgemm_nt((const bf16*)a, k, w_nk, (const bf16*)scale, true, c, nullptr, 0, 1, m, n, k, resolve_stream(s));
     return dispatch_mfma<bf16, B_NT_FP8>((const bf16*)a, w_nk, (const bf16*)scale, nullptr, (bf16*)c, m, n, k, resolve_stream(s));
 }
 

@@ -215,13 +215,22 @@ pgk_status pgk_w8a16_gemm_kn(const void* a, const uint8_t* b_kn, const void* sca
  * makes for its M > 1 path (linear.py:173-179). */
 pgk_status pgk_w8a16_gemm_nk(const void* a, const uint8_t* w_nk, const void* scale, void* c, int m, int n, int k,
                              pgk_stream s);
-/* gemm_fp8_fp8_blockwise_sm120 (src/pygpukit/ops/matmul/fp8.py:270-343): fp8 x fp8 MFMA GEMM,
- * A_fp8[M,K] (scale_a[M/1? see DESIGN]) . W_fp8[N,K]^T with 128-wide block scales, bf16 out.
- * Activation quantisation policy is defined by this build (parity-unpinned in the reference). */
+/* gemm_fp8_fp8_blockwise_sm120 (src/pygpukit/ops/matmul/fp8.py:288-343; its native side is CUTLASS and absent
+ * from the checkout): fp8 x fp8 MFMA GEMM with 128-wide block scales,
+ *   C[m][n] = sum_kb a_scale[m][kb] * w_scale[n/128][kb] * sum_{k in kb} E4M3(a[m][k]) * E4M3(w[n][k]).
+ * a_fp8 [M,K] codes with a_scale [M, K/128] fp32 (one scale per row per 128 k); w_fp8_nk [N,K] codes with
+ * w_scale [ceil(N/128), K/128] bf16 (the LinearFP8 layout, linear.py:149-160); C bf16 [M,N].  K % 128 == 0. */
 pgk_status pgk_gemm_fp8_nt(const uint8_t* a_fp8, const float* a_scale, const uint8_t* w_fp8_nk, const void* w_scale,
                            void* c, int m, int n, int k, pgk_stream s);
-/* per-row-block (1 x 128) e4m3 quantisation of bf16 activations for pgk_gemm_fp8_nt */
-pgk_status pgk_quantize_fp8_rows(const void* x_bf16, uint8_t* out_fp8, float* out_scale, int m, int k, pgk_stream s);
+/* Activation quantiser for pgk_gemm_fp8_nt (the fp32-in "auto-quantise" half of matmul_fp8, fp8.py:20-83):
+ * per (row, 128-k block) scale = absmax/448 (1 for an all-zero block), codes = RNE e4m3 of x/scale.
+ * dt = PGK_BF16 / PGK_F16 / PGK_F32. */
+pgk_status pgk_quantize_fp8_rows(const void* x, uint8_t* out_fp8, float* out_scale, int m, int k, pgk_dtype dt,
+                                 pgk_stream s);
+/* Weight quantiser: per 128x128 block scale = bf16(absmax/448), codes = RNE e4m3 of w/scale - the LinearFP8
+ * storage format (loader.py:228-252 reads it from checkpoints; this builds it from bf16 weights on device). */
+pgk_status pgk_quantize_fp8_blocks(const void* w_bf16, uint8_t* out_fp8, void* out_scale_bf16, int n, int k,
+                                   pgk_stream s);
 
 /* ------------------------------------------------------------------- attention ------ */
 /* ops.cuh:287-290 sdpa_causal(Q[Hq,q,D], K[Hkv,kv,D], V, scale<=0 -> 1/sqrt(D)), mask
@@ -252,7 +261,9 @@ typedef struct {
     int max_seq_len;      /* KV-cache rows per sequence */
     int max_batch;        /* independent sequences resident on this GPU */
     float norm_eps, rope_theta;
-    int weight_format;    /* 0 = bf16 linears, 1 = fp8-e4m3 linears with 128x128 bf16 block scales */
+    int weight_format;    /* 0 = bf16 linears, 1 = fp8-e4m3 linears with 128x128 bf16 block scales (w8a16),
+                           * 2 = as 1, and prefill of > 128 tokens also quantises activations per row per 128 k
+                           *     and runs the projections on the fp8 x fp8 MFMA GEMM (decode stays w8a16) */
     int use_qk_norm;
 } pgk_model_config_t;
 

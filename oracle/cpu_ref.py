@@ -379,6 +379,46 @@ def quantize_fp8_e4m3_block(w: np.ndarray, block_size=(128, 128)):
     return code.reshape(H, W), scale_bits
 
 
+def _rne_e4m3_codes(x: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> OCP e4m3 code (|x| clamped to 448; negative zero kept as 0x80,
+    as the hardware conversion leaves it)."""
+    table = fp8_e4m3_table()[:0x7F]
+    mag = np.minimum(np.abs(x), np.float32(448.0))
+    idx = np.clip(np.searchsorted(table, mag.ravel(), side="left").reshape(mag.shape), 0, 0x7E)
+    lo = np.clip(idx - 1, 0, 0x7E)
+    d_lo, d_hi = np.abs(table[lo] - mag), np.abs(table[idx] - mag)
+    pick_lo = np.where(d_lo == d_hi, (lo % 2) == 0, d_lo < d_hi)
+    code = np.where(pick_lo, lo, idx).astype(np.uint8)
+    return np.where(np.signbit(x), code | 0x80, code).astype(np.uint8)
+
+
+def quantize_fp8_rows(x: np.ndarray):
+    """[build-defined; the reference's auto-quantising matmul_fp8 (src/pygpukit/ops/matmul/fp8.py:20-70) has no
+    native side in the checkout] activation quantiser of the fp8 x fp8 GEMM: per (row, 128-k block)
+    scale = absmax/448 in fp32 (1 for an all-zero block), code = RNE e4m3 of x/scale (fp32 division).
+    x fp32 [M,K]; returns (codes uint8 [M,K], scale fp32 [M,K/128])."""
+    M, K = x.shape
+    xb = x.astype(np.float32).reshape(M, K // 128, 128)
+    absmax = np.abs(xb).max(axis=2)
+    scale = np.where(absmax > 0, absmax / np.float32(448.0), np.float32(1.0)).astype(np.float32)
+    q = (xb / scale[:, :, None]).astype(np.float32)
+    return _rne_e4m3_codes(q).reshape(M, K), scale
+
+
+def gemm_fp8_blockwise(a_codes: np.ndarray, a_scale: np.ndarray, w_codes: np.ndarray, w_scale_bits: np.ndarray) -> np.ndarray:
+    """[build-defined; restates the blockwise-scaled contract of gemm_fp8_fp8_blockwise_sm120,
+    src/pygpukit/ops/matmul/fp8.py:288-343]  C[m][n] = sum_kb sa[m][kb] * sw[n/128][kb] * sum_{k in kb} A[m][k] W[n][k],
+    evaluated in float64.  a_scale fp32 [M,K/128]; w_scale_bits bf16 bits [ceil(N/128),K/128].  Returns fp32 [M,N]."""
+    table = fp8_e4m3_table().astype(np.float64)
+    M, K = a_codes.shape
+    N = w_codes.shape[0]
+    a = table[a_codes].reshape(M, K // 128, 128) * a_scale.astype(np.float64)[:, :, None]
+    sw = bf16_bits_to_f32(w_scale_bits).astype(np.float64)
+    sw_rows = np.repeat(sw, 128, axis=0)[:N]                       # [N, K/128]
+    w = table[w_codes].reshape(N, K // 128, 128) * sw_rows[:, :, None]
+    return (a.reshape(M, K) @ w.reshape(N, K).T).astype(np.float32)
+
+
 def gemv_bf16(a_bits: np.ndarray, b_bits: np.ndarray) -> np.ndarray:
     """[kernel-defined] native/ops/matmul/gemv/bf16_bf16/sm120/bf16_opt.cuh:56-127:
     C[N] = A[K] . B[N,K]^T, bf16 in, fp32 accumulate, bf16 out.  Returns fp32 (unrounded)

@@ -713,7 +713,8 @@ template <int D>
 __global__ __launch_bounds__(256) void qknorm_rope_kvwrite_kernel(bf16* qkv, const bf16* q_gamma, const bf16* k_gamma,
                                                                   float eps, const float* rope_cos,
                                                                   const float* rope_sin, bf16* kcache, bf16* vcache,
-                                                                  int n, int hq, int hkv, int max_seq, int start_pos) {
+                                                                  int n, int hq, int hkv, int max_seq, int start_pos,
+                                                                  const float* slabs, int nslabs) {
     constexpr int LPR = D / 8, HALF = D / 2, VPB = 256 / LPR;
     const int nslots = hq + 2 * hkv;
     const long long vec = (long long)blockIdx.x * VPB + threadIdx.x / LPR;
@@ -724,7 +725,22 @@ __global__ __launch_bounds__(256) void qknorm_rope_kvwrite_kernel(bf16* qkv, con
     bf16* src = qkv + (size_t)s * nslots * D + (size_t)hh * D + sub * 8;
     float x[8];
     Vec<bf16> raw;
-    raw.load(src);
+    if (nslabs > 0) {
+        // the projection arrived as split-K fp32 partials: sum them and round to bf16, as the projection's
+        // own bf16 store would have
+        const size_t off = (size_t)s * nslots * D + (size_t)hh * D + sub * 8, stride = (size_t)n * nslots * D;
+        float4 a0 = *reinterpret_cast<const float4*>(slabs + off), a1 = *reinterpret_cast<const float4*>(slabs + off + 4);
+        for (int k = 1; k < nslabs; ++k) {
+            const float4 b0 = *reinterpret_cast<const float4*>(slabs + k * stride + off);
+            const float4 b1 = *reinterpret_cast<const float4*>(slabs + k * stride + off + 4);
+            a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+            a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+        }
+        const float f[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        raw.from_float(f);
+    } else {
+        raw.load(src);
+    }
     raw.to_float(x);
     const int pos = start_pos + s;
     const bool is_q = hh < hq, is_k = !is_q && hh < hq + hkv;
@@ -765,14 +781,30 @@ __global__ __launch_bounds__(256) void qknorm_rope_kvwrite_kernel(bf16* qkv, con
 }
 
 // act[s][i] = silu(gu[s][i]) * gu[s][I+i]   (bf16 in/out, fp32 math)
-__global__ void swiglu_rows_kernel(const bf16* gu, bf16* act, int n, int I) {
+// With nslabs > 0 the gate_up projection arrives as split-K fp32 partials [nslabs][n][2I] (summed, rounded to bf16).
+__global__ void swiglu_rows_kernel(const bf16* gu, bf16* act, int n, int I, const float* slabs, int nslabs) {
     const size_t total = (size_t)n * I / 8;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += stride) {
         const size_t s = t / (I / 8), c = t % (I / 8);
         Vec<bf16> g, u;
-        g.load(gu + s * 2 * I + c * 8);
-        u.load(gu + s * 2 * I + I + c * 8);
+        if (nslabs > 0) {
+            const size_t og = s * 2 * I + c * 8, ou = og + I, sst = (size_t)n * 2 * I;
+            float sg[8], su[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sg[j] = 0.f; su[j] = 0.f; }
+            for (int k = 0; k < nslabs; ++k) {
+                const float4 g0 = *reinterpret_cast<const float4*>(slabs + k * sst + og), g1 = *reinterpret_cast<const float4*>(slabs + k * sst + og + 4);
+                const float4 u0 = *reinterpret_cast<const float4*>(slabs + k * sst + ou), u1 = *reinterpret_cast<const float4*>(slabs + k * sst + ou + 4);
+                sg[0] += g0.x; sg[1] += g0.y; sg[2] += g0.z; sg[3] += g0.w; sg[4] += g1.x; sg[5] += g1.y; sg[6] += g1.z; sg[7] += g1.w;
+                su[0] += u0.x; su[1] += u0.y; su[2] += u0.z; su[3] += u0.w; su[4] += u1.x; su[5] += u1.y; su[6] += u1.z; su[7] += u1.w;
+            }
+            g.from_float(sg);
+            u.from_float(su);
+        } else {
+            g.load(gu + s * 2 * I + c * 8);
+            u.load(gu + s * 2 * I + I + c * 8);
+        }
         float gf[8], uf[8];
         g.to_float(gf);
         u.to_float(uf);
@@ -1170,7 +1202,10 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     // + split-K slabs of the N = hidden projections on the weight-streaming path (n <= 128)
     const bool ws = n <= 128;
     const int s_o = ws ? wsgemm_pick_splits(H, QD, true) : 1, s_d = ws ? wsgemm_pick_splits(H, I, true) : 1;
-    const size_t slab_elems = (size_t)(s_o > s_d ? s_o : s_d) * n * H;
+    const int s_qkv = ws ? wsgemm_pick_splits(NQKV, H, true) : 1, s_gu = ws ? wsgemm_pick_splits(2 * I, H, true) : 1;
+    size_t slab_elems = (size_t)(s_o > s_d ? s_o : s_d) * n * H;
+    if (s_qkv > 1 && (size_t)s_qkv * n * NQKV > slab_elems) slab_elems = (size_t)s_qkv * n * NQKV;
+    if (s_gu > 1 && (size_t)s_gu * n * 2 * I > slab_elems) slab_elems = (size_t)s_gu * n * 2 * I;
     const size_t need = (size_t)n * H * 4 + ((size_t)n * H + (size_t)n * NQKV + (size_t)n * QD + (size_t)n * 2 * I + (size_t)n * I) * 2 +
                         (ws ? slab_elems * 4 : 0) + 512;
     if (need > e->pf_bytes) {
@@ -1205,8 +1240,10 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
         pending = splits;
         return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, slabs, nullptr, 1, splits, n, N_, K_, st);
     };
-    auto proj_store = [&](const bf16* x_in, const void* w, const void* sc, bf16* out_, int N_, int K_) -> pgk_status {
+    // with splits > 1 the result is left as fp32 split-K slabs for the consumer kernel to sum
+    auto proj_store = [&](const bf16* x_in, const void* w, const void* sc, bf16* out_, int N_, int K_, int splits) -> pgk_status {
         if (!ws) return engine_gemm_nt(x_in, w, (const bf16*)sc, fp8, out_, false, n, N_, K_, st);
+        if (splits > 1) return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, slabs, nullptr, 1, splits, n, N_, K_, st);
         return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, out_, nullptr, 0, 1, n, N_, K_, st);
     };
     auto norm = [&](const bf16* gamma) -> pgk_status {
@@ -1223,17 +1260,19 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
         bf16* kc = e->kcache + (size_t)l * e->kv_layer_elems() + (size_t)seq * c.num_kv_heads * c.max_seq_len * D;
         bf16* vc = e->vcache + (size_t)l * e->kv_layer_elems() + (size_t)seq * c.num_kv_heads * c.max_seq_len * D;
         if (pgk_status r = norm((const bf16*)L.attn_norm)) return r;
-        if (pgk_status r = proj_store(x, L.w_qkv, L.s_qkv, qkv, NQKV, H)) return r;
+        if (pgk_status r = proj_store(x, L.w_qkv, L.s_qkv, qkv, NQKV, H, s_qkv)) return r;
         {
             const int nslots = c.num_heads + 2 * c.num_kv_heads;
             const bf16* qg = c.use_qk_norm ? (const bf16*)L.q_norm : nullptr;
             const bf16* kg = c.use_qk_norm ? (const bf16*)L.k_norm : nullptr;
             if (D == 128)
                 qknorm_rope_kvwrite_kernel<128><<<ceil_div((long long)n * nslots, 16), 256, 0, st>>>(
-                    qkv, qg, kg, c.norm_eps, e->rope_cos, e->rope_sin, kc, vc, n, c.num_heads, c.num_kv_heads, c.max_seq_len, start_pos);
+                    qkv, qg, kg, c.norm_eps, e->rope_cos, e->rope_sin, kc, vc, n, c.num_heads, c.num_kv_heads, c.max_seq_len, start_pos,
+                    slabs, s_qkv > 1 ? s_qkv : 0);
             else
                 qknorm_rope_kvwrite_kernel<64><<<ceil_div((long long)n * nslots, 32), 256, 0, st>>>(
-                    qkv, qg, kg, c.norm_eps, e->rope_cos, e->rope_sin, kc, vc, n, c.num_heads, c.num_kv_heads, c.max_seq_len, start_pos);
+                    qkv, qg, kg, c.norm_eps, e->rope_cos, e->rope_sin, kc, vc, n, c.num_heads, c.num_kv_heads, c.max_seq_len, start_pos,
+                    slabs, s_qkv > 1 ? s_qkv : 0);
             PGK_LAUNCH_CHECK();
         }
         if (pgk_status r = pgk_sdpa_causal(qkv, kc, vc, attn, c.num_heads, c.num_kv_heads, n, kv_len, D, 0.f, D, NQKV,
@@ -1241,8 +1280,8 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
             return r;
         if (pgk_status r = proj_accum(attn, L.w_o, L.s_o, H, QD, s_o)) return r;
         if (pgk_status r = norm((const bf16*)L.mlp_norm)) return r;
-        if (pgk_status r = proj_store(x, L.w_gate_up, L.s_gate_up, gu, 2 * I, H)) return r;
-        swiglu_rows_kernel<<<ceil_div((long long)n * I / 8, 256) > 2048 ? 2048 : ceil_div((long long)n * I / 8, 256), 256, 0, st>>>(gu, act, n, I);
+        if (pgk_status r = proj_store(x, L.w_gate_up, L.s_gate_up, gu, 2 * I, H, s_gu)) return r;
+        swiglu_rows_kernel<<<ceil_div((long long)n * I / 8, 256) > 2048 ? 2048 : ceil_div((long long)n * I / 8, 256), 256, 0, st>>>(gu, act, n, I, slabs, s_gu > 1 ? s_gu : 0);
         PGK_LAUNCH_CHECK();
         if (pgk_status r = proj_accum(act, L.w_down, L.s_down, H, I, s_d)) return r;
     }

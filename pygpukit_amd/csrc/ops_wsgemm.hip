@@ -191,7 +191,10 @@ int wsgemm_pick_splits(int N, int K, bool allow_split) {
     const int max_s = K / WS_KT;
     if (s > max_s) s = max_s;
     if (s > 16) s = 16;
-    return s < 1 ? 1 : s;
+    if (s < 1) s = 1;
+    // normalise to a split count that tiles K in whole LDS tiles (what wsgemm_nt will actually launch)
+    const int kps = ceil_div(ceil_div(K, s), WS_KT) * WS_KT;
+    return ceil_div(K, kps);
 }
 
 // A[M,K] bf16 (row stride lda), W[N,K]; mode 0: bf16 C (+bias); mode 1: fp32 slabs [splits][M][N]; mode 2: fp32 C += .

@@ -5,7 +5,8 @@ from pygpukit_amd.ops.embedding import (embedding_lookup, embedding_lookup_batch
                                        kv_cache_prefill_gqa, kv_cache_update_gqa, kv_cache_update_gqa_ptr)
 from pygpukit_amd.ops.matmul import (batched_matmul, gemm_w8a16_init_lut, gemv_bf16, gemv_bf16_opt_available, gemv_fp8_bf16,
                                     gemv_fp8_bf16_batched, linear_bias_gelu, matmul, matmul_nt, transpose, w8a16_gemm,
-                                    w8a16_gemm_nk, w8a16_gemm_sm120)
+                                    w8a16_gemm_nk, w8a16_gemm_sm120, matmul_fp8, matmul_fp8_sm120, gemm_fp8_fp8_blockwise_nt,
+                                    quantize_fp8_rows, quantize_fp8_blocks, fp8_available, fp8_init_lut)
 from pygpukit_amd.ops.nn import (bias_add_inplace, geglu, gelu, glu_packed, layernorm, relu2, rmsnorm, rmsnorm_residual, rope_inplace,
                                 rope_inplace_f32table, sdpa_causal, sdpa_causal_fixed_cache, sdpa_causal_fixed_cache_ptr,
                                 sdpa_causal_strided, sigmoid, silu, slice_rows_range_ptr, split_qkv_batch, swiglu, tanh)

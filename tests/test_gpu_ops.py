@@ -356,6 +356,89 @@ def test_w8a16_gemm_kn(m):
     assert rel_err(c[:8], c2) < 1e-2
 
 
+# ----------------------------------------------------------------------------- fp8 x fp8 GEMM
+def _fp8_vals(codes):
+    return O.fp8_e4m3_table()[codes]
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float32"])
+def test_quantize_fp8_rows_matches_oracle(dt):
+    rng = np.random.default_rng(21)
+    M, K = 37, 512
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.01, 30.0, (M, 1))).astype(np.float32)
+    x[3, 128:256] = 0.0            # an all-zero block: scale 1, codes 0
+    x[5, 7] = 1e-9                 # far below the block's smallest subnormal step
+    x = rounded(x, dt)
+    codes, scale = ops.quantize_fp8_rows(dev(x, dt))
+    rc, rs = O.quantize_fp8_rows(x)
+    np.testing.assert_array_equal(scale.to_numpy(), rs)          # fp32 absmax/448: bit-exact
+    np.testing.assert_array_equal(_fp8_vals(codes.to_numpy()), _fp8_vals(rc))   # same e4m3 value everywhere
+    assert np.all(codes.to_numpy()[3, 128:256] == 0) and scale.to_numpy()[3, 1] == 1.0
+
+
+def test_quantize_fp8_blocks_matches_oracle():
+    rng = np.random.default_rng(22)
+    N, K = 200, 384               # ragged last row-block
+    w = O.bf16_round((rng.standard_normal((N, K)) * 0.02).astype(np.float32))
+    codes, scale = ops.quantize_fp8_blocks(dev(w, "bfloat16"))
+    wp = np.zeros((256, K), np.float32)
+    wp[:N] = w
+    rc, rs = O.quantize_fp8_e4m3_block(wp)
+    np.testing.assert_array_equal(scale.to_numpy(), rs)
+    np.testing.assert_array_equal(_fp8_vals(codes.to_numpy()), _fp8_vals(rc[:N]))
+
+
+@pytest.mark.parametrize("shape", [(1, 128, 128), (100, 384, 512), (256, 256, 1024), (130, 200, 256)])
+def test_gemm_fp8_blockwise(shape):
+    """Same codes and scales on both sides: what is left is fp32 accumulation order (bar 1e-3; bf16 output rounding
+    alone is 2e-3 relative per element, ~1e-3 in L2)."""
+    M, N, K = shape
+    rng = np.random.default_rng(23)
+    a = (rng.standard_normal((M, K)) * rng.uniform(0.1, 4.0, (M, 1))).astype(np.float32)
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    a8, sa = O.quantize_fp8_rows(a)
+    npad = (N + 127) // 128 * 128
+    wp = np.zeros((npad, K), np.float32)
+    wp[:N] = w
+    w8, sw = O.quantize_fp8_e4m3_block(wp)
+    w8 = np.ascontiguousarray(w8[:N])
+    ref = O.gemm_fp8_blockwise(a8, sa, w8, sw)
+    c = host(ops.gemm_fp8_fp8_blockwise_nt(from_numpy(a8), from_numpy(w8), from_numpy(sa), from_numpy(sw)))
+    assert rel_err(c, ref) < 3e-3
+    # and against the unquantised product: the fp8 bar of BASELINE.json
+    assert rel_err(c, a @ w.T) < 5e-2
+
+
+def test_gemm_fp8_exact_integers_and_asymmetric_operand():
+    """Small-integer operands with unit scales are exact in e4m3 and in fp32: the result must be bit-exact, which
+    pins the A/B lane->k pairing and the C row/col map (an asymmetric W catches a transposed store)."""
+    rng = np.random.default_rng(24)
+    M, N, K = 48, 160, 256
+    table = O.fp8_e4m3_table()
+    ints = {float(v): c for c, v in enumerate(table[:0x7F]) if v == np.floor(v) and v <= 8}
+    ai = rng.integers(-4, 5, (M, K)).astype(np.float32)
+    wi = rng.integers(-4, 5, (N, K)).astype(np.float32)
+    wi[:, 0] = np.arange(N) % 5       # asymmetric
+    enc = lambda x: (np.vectorize(lambda v: ints[abs(float(v))])(x).astype(np.uint8) | np.where(x < 0, 0x80, 0).astype(np.uint8))
+    a8, w8 = enc(ai), enc(wi)
+    sa = np.ones((M, K // 128), np.float32)
+    sw = np.full((2, K // 128), 0x3F80, np.uint16)
+    c = host(ops.gemm_fp8_fp8_blockwise_nt(from_numpy(a8), from_numpy(w8), from_numpy(sa), from_numpy(sw)))
+    np.testing.assert_array_equal(c, O.bf16_round(ai @ wi.T))
+
+
+def test_matmul_fp8_auto_quantise():
+    rng = np.random.default_rng(25)
+    M, K, N = 64, 256, 192
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    b = (rng.standard_normal((K, N)) * 0.05).astype(np.float32)
+    c = ops.matmul_fp8(from_numpy(a), from_numpy(b))
+    assert c.dtype == float32 and c.shape == (M, N)
+    assert rel_err(c.to_numpy(), a @ b) < 5e-2
+    with pytest.raises(ValueError):
+        ops.matmul_fp8(from_numpy(a), from_numpy(b[:100]))
+
+
 # ----------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("tag", ["off", "sq", "dec"])
 def test_sdpa_golden_fp32(tag):

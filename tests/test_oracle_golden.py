@@ -177,3 +177,22 @@ def test_gpt2_small_config1_tokens():
     model = O.build_gpt2_ref(O.GPT2_SMALL, w)
     ids = model.generate([int(t) for t in g4["prompt"]], max_new_tokens=16, temperature=0.0, top_k=0, top_p=1.0)
     eq(ids, g4["tokens"])
+
+
+# ---- fp8 x fp8 blockwise GEMM restatement (build-defined contract, include/pgk_hip.h) ----------------------
+def test_fp8_row_quantiser_round_trip_and_gemm_identity():
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((5, 256)) * 3).astype(np.float32)
+    x[2, :128] = 0
+    codes, scale = O.quantize_fp8_rows(x)
+    assert codes.dtype == np.uint8 and scale.shape == (5, 2) and scale[2, 0] == 1.0
+    deq = O.fp8_e4m3_table()[codes].reshape(5, 2, 128) * scale[:, :, None]
+    # e4m3 keeps 3 mantissa bits: relative step 2^-3, half of it after rounding; absmax maps exactly to 448
+    assert np.max(np.abs(deq.reshape(5, 256) - x)) <= np.abs(x).max() * 2.0**-4
+    assert np.all(np.abs(O.fp8_e4m3_table()[codes]).max(axis=1) == 448.0)
+    # GEMM against an identity-like weight reproduces the dequantised activations
+    w = np.zeros((128, 256), np.float32)
+    w[np.arange(128), np.arange(128)] = 1.0
+    wc, ws = O.quantize_fp8_e4m3_block(w)
+    out = O.gemm_fp8_blockwise(codes, scale, wc, ws)
+    np.testing.assert_allclose(out, deq.reshape(5, 256)[:, :128] * (O.fp8_e4m3_table()[wc][0, 0] * O.bf16_bits_to_f32(ws)[0, 0]), rtol=1e-6)

@@ -1,0 +1,57 @@
+"""Time the C-ABI GEMMs at prefill shapes: TFLOP/s against the dense MFMA peak.
+usage: gemm_bench.py {bf16|w8a16|fp8} M N K [M N K ...]"""
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, '.')
+from pygpukit_amd import _hip
+
+PGK_BF16 = 2
+
+
+def dev(nbytes, fill=None):
+    p = C.c_void_p()
+    _hip.call("pgk_malloc", C.byref(p), nbytes)
+    if fill is not None:
+        _hip.call("pgk_memcpy_h2d", p, fill.ctypes.data_as(C.c_void_p), fill.nbytes, None)
+    return p
+
+
+def main():
+    kind = sys.argv[1]
+    dims = [int(x) for x in sys.argv[2:]]
+    _hip.require_device()
+    rng = np.random.default_rng(0)
+    for i in range(0, len(dims), 3):
+        M, N, K = dims[i:i + 3]
+        a16 = (rng.standard_normal((M, K)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        c = dev(M * N * 2)
+        if kind == "bf16":
+            w16 = (rng.standard_normal((N, K)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+            a, w = dev(a16.nbytes, a16), dev(w16.nbytes, w16)
+            run = lambda: _hip.call("pgk_gemm_nt", a, w, None, c, M, N, K, PGK_BF16, None)
+        else:
+            w8 = rng.integers(0, 0x7E, (N, K), dtype=np.uint8)
+            sc = np.full((N // 128, K // 128), 0x3C00, np.uint16)  # bf16 2^-7
+            w, s = dev(w8.nbytes, w8), dev(sc.nbytes, sc)
+            if kind == "w8a16":
+                a = dev(a16.nbytes, a16)
+                run = lambda: _hip.call("pgk_w8a16_gemm_nk", a, w, s, c, M, N, K, None)
+            else:
+                a8 = rng.integers(0, 0x7E, (M, K), dtype=np.uint8)
+                asc = np.ones((M, K // 128), np.float32)
+                a, sa = dev(a8.nbytes, a8), dev(asc.nbytes, asc)
+                run = lambda: _hip.call("pgk_gemm_fp8_nt", a, sa, w, s, c, M, N, K, None)
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        _hip.call("pgk_event_create", C.byref(e0)); _hip.call("pgk_event_create", C.byref(e1))
+        for _ in range(5): run()
+        reps = 20
+        _hip.call("pgk_event_record", e0, None)
+        for _ in range(reps): run()
+        _hip.call("pgk_event_record", e1, None)
+        _hip.call("pgk_event_sync", e1)
+        ms = C.c_float()
+        _hip.call("pgk_event_elapsed_ms", e0, e1, C.byref(ms))
+        us = ms.value * 1e3 / reps
+        print(f"{kind} M={M} N={N} K={K}: {us:9.1f} us  {2.0 * M * N * K / us / 1e6:8.1f} TFLOP/s", flush=True)
+
+
+main()

@@ -107,8 +107,28 @@ def main() -> None:
     cp = ControlPlane()
     if cp.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={cp.world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    _hip.call("pgk_device_set", cp.local_rank)
-    comm = RcclComm(cp) if cp.world > 1 else None
+    ndev = _hip.device_count()
+    _hip.call("pgk_device_set", cp.local_rank % max(ndev, 1))
+    # RCCL carries the one-time weight broadcast and the end-of-run token gather.  The decode path itself is pure
+    # data parallelism (no collective inside a step), so if RCCL cannot come up (e.g. two ranks sharing one GPU
+    # in a rehearsal) every rank draws the same seeded weights itself and the tokens travel over the gloo
+    # control plane instead; the JSON line says which happened.
+    comm, rccl_note = None, None
+    if cp.world > 1:
+        # every rank takes the same branch at every step: collectives on the control plane must stay matched
+        if cp.min_over_ranks(1 if cp.local_rank < ndev else 0) == 0:
+            rccl_note = f"a rank has no GPU of its own ({ndev} visible, {cp.world} ranks)"
+        else:
+            ok = 1
+            try:
+                comm = RcclComm(cp)
+            except Exception as e:  # noqa: BLE001
+                ok, rccl_note = 0, f"{type(e).__name__}: {e}"
+            if cp.min_over_ranks(ok) == 0:
+                if comm is not None:
+                    comm.destroy()
+                comm = None
+            rccl_note = cp.first_note(rccl_note)
 
     cfg = dict(S.QWEN3_0_6B)
     if args.layers:
@@ -118,9 +138,9 @@ def main() -> None:
     t_setup = time.perf_counter()
 
     # ---- weights: rank 0 draws them, every other rank receives them over RCCL (xGMI broadcast) ----
-    weights = S.make_qwen3_weights(cfg, seed=args.seed) if cp.rank == 0 or cp.world == 1 else None
+    weights = S.make_qwen3_weights(cfg, seed=args.seed) if cp.rank == 0 or comm is None else None
     bcast_s = None
-    if cp.world == 1:
+    if comm is None:
         eng = S.build_engine_from_weights(cfg, weights, max_seq_len=max_seq, max_batch=B, weight_format=args.weight_format)
     else:
         from pygpukit_amd.core.array import GPUArray
@@ -181,19 +201,10 @@ def main() -> None:
     # ---- decode: whole-step hipGraph, state in device memory ----
     eng.set_state(first, [P] * B)
     eng.capture(B)
-    tok_dev, _ = eng.state_arrays(B)
-    gathered = None
-    if comm is not None:
-        from pygpukit_amd.core.array import GPUArray
-        from pygpukit_amd.core.dtypes import int32
-
-        gathered = GPUArray((cp.world * B,), int32)
 
     def run(n):
         for _ in range(n):
-            eng.replay(1)
-            if comm is not None:
-                comm.all_gather(tok_dev, gathered)  # 4*B bytes per rank, on the same stream, no host sync
+            eng.replay(1)   # one whole-step graph launch; no collective and no host sync inside a step
 
     run(W)
     _hip.call("pgk_device_sync")
@@ -211,6 +222,24 @@ def main() -> None:
     wall_max = cp.max_over_ranks(wall)
     dev_ms_max = cp.max_over_ranks(ms.value)
     tokens = eng.read_tokens(B, min(W + K, 4096))
+    # the harness's view of the whole batch: every rank's token log gathered once, after the timed steps
+    # (RCCL all-gather of the device-resident log; gloo when RCCL is not up)
+    t0 = time.perf_counter()
+    if comm is not None:
+        from pygpukit_amd.core.array import GPUArray
+        from pygpukit_amd.core.dtypes import int32
+        from pygpukit_amd.core.factory import from_numpy
+
+        mine_log = from_numpy(np.ascontiguousarray(tokens, dtype=np.int32))
+        all_log = GPUArray((cp.world,) + tuple(tokens.shape), int32)
+        comm.all_gather(mine_log, all_log)
+        _hip.call("pgk_device_sync")
+        all_tokens = all_log.to_numpy()
+    elif cp.world > 1:
+        all_tokens = np.stack(cp.all_gather_array(np.ascontiguousarray(tokens, dtype=np.int32)))
+    else:
+        all_tokens = tokens[None]
+    gather_s = time.perf_counter() - t0
 
     # ---- per-kernel timing (eager, event after every kernel) for the roofline objects ----
     prof = eng.profile_step(B, 8)
@@ -255,6 +284,11 @@ def main() -> None:
         "first_tokens": [int(t) for t in tokens[: min(8, len(tokens)), 0]],
         "setup_s": time.perf_counter() - t_setup,
     }
+    if cp.world > 1:
+        result["token_gather"] = {"seconds": gather_s, "bytes_per_rank": int(tokens.nbytes), "via": "rccl all_gather" if comm is not None else "gloo",
+                                  "ranks_agree_on_shape": bool(all_tokens.shape[0] == cp.world)}
+        if rccl_note:
+            result["rccl"] = f"not used ({rccl_note}); weights drawn per rank from the same seed"
     if bcast_s is not None:
         result["weight_broadcast"] = {"seconds": bcast_s, "GB": nbytes / 1e9, "GBps": nbytes / 1e9 / bcast_s}
     if args.layers:

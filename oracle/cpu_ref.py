@@ -413,8 +413,10 @@ def gemm_fp8_blockwise(a_codes: np.ndarray, a_scale: np.ndarray, w_codes: np.nda
     M, K = a_codes.shape
     N = w_codes.shape[0]
     a = table[a_codes].reshape(M, K // 128, 128) * a_scale.astype(np.float64)[:, :, None]
-    sw = bf16_bits_to_f32(w_scale_bits).astype(np.float64)
-    sw_rows = np.repeat(sw, 128, axis=0)[:N]                       # [N, K/128]
+    if w_scale_bits.dtype == np.uint16:
+        sw_rows = np.repeat(bf16_bits_to_f32(w_scale_bits).astype(np.float64), 128, axis=0)[:N]   # [N, K/128]
+    else:
+        sw_rows = w_scale_bits.astype(np.float64)                  # already expanded per row: fp32 [N, K/128]
     w = table[w_codes].reshape(N, K // 128, 128) * sw_rows[:, :, None]
     return (a.reshape(M, K) @ w.reshape(N, K).T).astype(np.float32)
 
@@ -457,6 +459,35 @@ class RefLinear:
         if self.bias is not None:
             y = bias_add(y, self.bias)
         return y
+
+
+class RefLinearFP8A8:
+    """[build-defined] Linear on the fp8 x fp8 path (weight_format 2 of include/pgk_hip.h): the bf16 activations are
+    quantised per (row, 128 k) by quantize_fp8_rows and multiplied with the block-scaled e4m3 weight by
+    gemm_fp8_blockwise.  `scale_rows` is the 128x128 block scale expanded to one fp32 row per weight row, so a
+    row slice of a fused (qkv / gate_up) matrix keeps the scales of the block it was quantised in."""
+
+    def __init__(self, codes: np.ndarray, scale_rows: np.ndarray):
+        self.codes, self.scale_rows = codes, scale_rows
+
+    def __call__(self, x):
+        a_codes, a_scale = quantize_fp8_rows(bf16_round(np.asarray(x, dtype=np.float32)))
+        return gemm_fp8_blockwise(a_codes, a_scale, self.codes, self.scale_rows)
+
+
+def fp8a8_linears(mats: list) -> list:
+    """Quantise the row-concatenation of `mats` (as the engine fuses q|k|v and gate|up) per 128x128 block and return
+    one RefLinearFP8A8 per input matrix."""
+    fused = np.concatenate(mats, axis=0).astype(np.float32)
+    n = fused.shape[0]
+    pad = (-n) % 128
+    codes, sbits = quantize_fp8_e4m3_block(np.concatenate([fused, np.zeros((pad, fused.shape[1]), np.float32)], axis=0))
+    rows = np.repeat(bf16_bits_to_f32(sbits), 128, axis=0)[:n]
+    out, r = [], 0
+    for m in mats:
+        out.append(RefLinearFP8A8(codes[r:r + m.shape[0]], rows[r:r + m.shape[0]]))
+        r += m.shape[0]
+    return out
 
 
 class RefNorm:
@@ -653,12 +684,25 @@ def build_qwen3_ref(cfg: dict, weights: dict, max_pos: int = 2048) -> RefModel:
         attn = RefAttention(lw["q"], lw["k"], lw["v"], lw["o"], num_heads=cfg["num_heads"],
                             num_kv_heads=cfg["num_kv_heads"], head_dim=cfg["head_dim"],
                             use_rope=True, rope_theta=cfg["rope_theta"], max_position_embeddings=max_pos,
-                            q_norm=RefNorm(lw["q_norm"], None, "rmsnorm", eps),
-                            k_norm=RefNorm(lw["k_norm"], None, "rmsnorm", eps))
+                            q_norm=RefNorm(lw["q_norm"], None, "rmsnorm", eps) if "q_norm" in lw else None,
+                            k_norm=RefNorm(lw["k_norm"], None, "rmsnorm", eps) if "k_norm" in lw else None)
         mlp = RefMLP("silu", gate=lw["gate"], up=lw["up"], down=lw["down"])
         blocks.append(RefBlock(RefNorm(lw["attn_norm"], None, "rmsnorm", eps), attn,
                                RefNorm(lw["mlp_norm"], None, "rmsnorm", eps), mlp))
     return RefModel(weights["embed"], blocks, RefNorm(weights["final_norm"], None, "rmsnorm", eps))
+
+
+def build_qwen3_ref_fp8a8(cfg: dict, weights: dict, max_pos: int = 2048) -> RefModel:
+    """build_qwen3_ref with every projection on the fp8 x fp8 path (prefill of weight_format 2).  Note the padding
+    caveat of fp8a8_linears: a fused matrix whose row count is not a multiple of 128 is quantised with zero rows
+    appended, which leaves the block absmax - and so the codes - unchanged."""
+    model = build_qwen3_ref(cfg, weights, max_pos)
+    for blk, lw in zip(model.blocks, weights["layers"]):
+        blk.attn.q_proj, blk.attn.k_proj, blk.attn.v_proj = fp8a8_linears([lw["q"], lw["k"], lw["v"]])
+        (blk.attn.o_proj,) = fp8a8_linears([lw["o"]])
+        blk.mlp.gate_proj, blk.mlp.up_proj = fp8a8_linears([lw["gate"], lw["up"]])
+        (blk.mlp.down_proj,) = fp8a8_linears([lw["down"]])
+    return model
 
 
 def make_gpt2_weights(cfg: dict, seed: int = 0, std: float = 0.02) -> dict:

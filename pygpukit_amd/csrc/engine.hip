@@ -35,6 +35,9 @@ namespace pgk {
 pgk_status engine_gemm_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, void* C, bool accum_f32, int M,
                           int N, int K, hipStream_t st);
 int wsgemm_pick_splits(int N, int K, bool allow_split);
+pgk_status gemm_fp8_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, void* c, bool accum_f32, int M,
+                       int N, int K, hipStream_t st);
+pgk_status quantize_fp8_rows_bf16(const bf16* x, uint8_t* out, float* scale, int M, int K, hipStream_t st);
 pgk_status wsgemm_nt(const bf16* a, int lda, const void* w, const bf16* wscale, bool fp8, void* c, const bf16* bias, int mode,
                      int splits, int M, int N, int K, hipStream_t st);
 
@@ -1069,7 +1072,7 @@ static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* la
 }
 
 static pgk_status decode_step(Engine* e, int batch, hipStream_t st, int* launches) {
-    if (e->cfg.weight_format == 1) return decode_step_impl<fp8e4m3>(e, batch, st, launches);
+    if (e->cfg.weight_format != 0) return decode_step_impl<fp8e4m3>(e, batch, st, launches);
     return decode_step_impl<bf16>(e, batch, st, launches);
 }
 
@@ -1203,11 +1206,12 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     const bool ws = n <= 128;
     const int s_o = ws ? wsgemm_pick_splits(H, QD, true) : 1, s_d = ws ? wsgemm_pick_splits(H, I, true) : 1;
     const int s_qkv = ws ? wsgemm_pick_splits(NQKV, H, true) : 1, s_gu = ws ? wsgemm_pick_splits(2 * I, H, true) : 1;
+    const int maxk = I > QD ? (I > H ? I : H) : (QD > H ? QD : H);
     size_t slab_elems = (size_t)(s_o > s_d ? s_o : s_d) * n * H;
     if (s_qkv > 1 && (size_t)s_qkv * n * NQKV > slab_elems) slab_elems = (size_t)s_qkv * n * NQKV;
     if (s_gu > 1 && (size_t)s_gu * n * 2 * I > slab_elems) slab_elems = (size_t)s_gu * n * 2 * I;
     const size_t need = (size_t)n * H * 4 + ((size_t)n * H + (size_t)n * NQKV + (size_t)n * QD + (size_t)n * 2 * I + (size_t)n * I) * 2 +
-                        (ws ? slab_elems * 4 : 0) + 512;
+                        (ws ? slab_elems * 4 : 0) + 512 + (c.weight_format == 2 ? (size_t)n * maxk + (size_t)n * (maxk / 128) * 4 + 512 : 0);
     if (need > e->pf_bytes) {
         if (e->pf) PGK_CHECK_HIP(hipStreamSynchronize(st));
         if (e->pf) pgk_free(e->pf);
@@ -1224,7 +1228,8 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
         PGK_REQUIRE(h_tokens[i] >= 0 && h_tokens[i] < c.vocab_size, "pgk_engine_prefill: token %d out of range", h_tokens[i]);
     PGK_CHECK_HIP(hipMemcpyAsync(e->pf_tokens, h_tokens, (size_t)n * 4, hipMemcpyHostToDevice, st));
     PGK_CHECK_HIP(hipStreamSynchronize(st));  // h_tokens may be pageable: make the copy complete before returning control
-    const bool fp8 = c.weight_format == 1;
+    const bool fp8 = c.weight_format != 0;
+    const bool fp8act = c.weight_format == 2 && n > 128;   // fp8 x fp8 MFMA projections, activations quantised on the fly
     char* p = (char*)e->pf;
     float* h32 = (float*)p; p += (size_t)n * H * 4;
     bf16* x = (bf16*)p; p += (size_t)n * H * 2;
@@ -1233,8 +1238,14 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     bf16* gu = (bf16*)p; p += (size_t)n * 2 * I * 2;
     bf16* act = (bf16*)p; p += (size_t)n * I * 2;
     float* slabs = (float*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    uint8_t* q8 = (uint8_t*)(((uintptr_t)slabs + (ws ? slab_elems * 4 : 0) + 255) & ~(uintptr_t)255);   // fp8 activations [n][maxk]
+    float* q8s = (float*)(q8 + (size_t)n * maxk);                                                          // their scales [n][maxk/128]
     int pending = 0;   // split-K slabs of the previous projection still to be added into h32 by the next norm
     auto proj_accum = [&](const bf16* x_in, const void* w, const void* sc, int N_, int K_, int splits) -> pgk_status {
+        if (fp8act) {
+            if (pgk_status r = quantize_fp8_rows_bf16(x_in, q8, q8s, n, K_, st)) return r;
+            return gemm_fp8_nt(q8, q8s, (const uint8_t*)w, (const bf16*)sc, h32, true, n, N_, K_, st);
+        }
         if (!ws) return engine_gemm_nt(x_in, w, (const bf16*)sc, fp8, h32, true, n, N_, K_, st);
         if (splits == 1) return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, h32, nullptr, 2, 1, n, N_, K_, st);
         pending = splits;
@@ -1242,6 +1253,10 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     };
     // with splits > 1 the result is left as fp32 split-K slabs for the consumer kernel to sum
     auto proj_store = [&](const bf16* x_in, const void* w, const void* sc, bf16* out_, int N_, int K_, int splits) -> pgk_status {
+        if (fp8act) {
+            if (pgk_status r = quantize_fp8_rows_bf16(x_in, q8, q8s, n, K_, st)) return r;
+            return gemm_fp8_nt(q8, q8s, (const uint8_t*)w, (const bf16*)sc, out_, false, n, N_, K_, st);
+        }
         if (!ws) return engine_gemm_nt(x_in, w, (const bf16*)sc, fp8, out_, false, n, N_, K_, st);
         if (splits > 1) return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, slabs, nullptr, 1, splits, n, N_, K_, st);
         return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, out_, nullptr, 0, 1, n, N_, K_, st);

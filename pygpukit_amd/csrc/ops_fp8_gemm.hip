@@ -44,31 +44,40 @@ __global__ __launch_bounds__(F8_THREADS) void gemm_fp8_kernel(const uint8_t* A, 
     const int m0 = blockIdx.y * F8_BM, n0 = blockIdx.x * F8_BN;
     const int KB = K >> 7;
 
-    // staging registers: 4 + 4 chunks of 16 B, and this thread's row scale
-    uint4 ra[4], rb[4];
-    float rs;
-    const size_t a_row[4] = {(size_t)min(m0 + (tid >> 3), M - 1) * K, (size_t)min(m0 + 32 + (tid >> 3), M - 1) * K,
-                             (size_t)min(m0 + 64 + (tid >> 3), M - 1) * K, (size_t)min(m0 + 96 + (tid >> 3), M - 1) * K};
-    const size_t b_row[4] = {(size_t)min(n0 + (tid >> 3), N - 1) * K, (size_t)min(n0 + 32 + (tid >> 3), N - 1) * K,
-                             (size_t)min(n0 + 64 + (tid >> 3), N - 1) * K, (size_t)min(n0 + 96 + (tid >> 3), N - 1) * K};
-    const size_t s_row = (size_t)min(m0 + (tid & 127), M - 1) * KB;
+    // staging registers: 4 + 4 chunks of 16 B, and this thread's row scale.  Named scalars, not arrays: at this
+    // register pressure hipcc leaves a staging ARRAY in scratch memory (a load-wait-scratch_store per chunk).
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    float rs_a;
+    bf16 rs_w;   // raw: multiplied in store_tiles, touching them at load time would drain the whole load queue
+    const int srow = tid >> 3, skc = tid & 7;
+    const uint8_t* a_p0 = A + (size_t)min(m0 + srow, M - 1) * K + skc * 16;
+    const uint8_t* a_p1 = A + (size_t)min(m0 + 32 + srow, M - 1) * K + skc * 16;
+    const uint8_t* a_p2 = A + (size_t)min(m0 + 64 + srow, M - 1) * K + skc * 16;
+    const uint8_t* a_p3 = A + (size_t)min(m0 + 96 + srow, M - 1) * K + skc * 16;
+    const uint8_t* b_p0 = W + (size_t)min(n0 + srow, N - 1) * K + skc * 16;
+    const uint8_t* b_p1 = W + (size_t)min(n0 + 32 + srow, N - 1) * K + skc * 16;
+    const uint8_t* b_p2 = W + (size_t)min(n0 + 64 + srow, N - 1) * K + skc * 16;
+    const uint8_t* b_p3 = W + (size_t)min(n0 + 96 + srow, N - 1) * K + skc * 16;
+    const float* sa_p = sa + (size_t)min(m0 + (tid & 127), M - 1) * KB;
     const bf16* sw_row = sw + (size_t)blockIdx.x * KB;
+    const int st_off = f8_off(srow, skc);   // rows srow + 32 i share the swizzle (32 % 8 == 0)
     auto load_tiles = [&](int kt) {
-        const int kbyte = kt * 128 + (tid & 7) * 16;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const uint4*>(A + a_row[i] + kbyte);
-            rb[i] = *reinterpret_cast<const uint4*>(W + b_row[i] + kbyte);
-        }
-        rs = sa[s_row + kt] * to_f(sw_row[kt]);
+        const size_t kb = (size_t)kt * 128;
+        ra0 = *reinterpret_cast<const uint4*>(a_p0 + kb); ra1 = *reinterpret_cast<const uint4*>(a_p1 + kb);
+        ra2 = *reinterpret_cast<const uint4*>(a_p2 + kb); ra3 = *reinterpret_cast<const uint4*>(a_p3 + kb);
+        rb0 = *reinterpret_cast<const uint4*>(b_p0 + kb); rb1 = *reinterpret_cast<const uint4*>(b_p1 + kb);
+        rb2 = *reinterpret_cast<const uint4*>(b_p2 + kb); rb3 = *reinterpret_cast<const uint4*>(b_p3 + kb);
+        rs_a = sa_p[kt];
+        rs_w = sw_row[kt];
     };
     auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4*>(As(buf) + f8_off(i * 32 + (tid >> 3), tid & 7)) = ra[i];
-            *reinterpret_cast<uint4*>(Bs(buf) + f8_off(i * 32 + (tid >> 3), tid & 7)) = rb[i];
-        }
-        if (tid < F8_BM) Ss(buf)[tid] = rs;
+        char* a = As(buf) + st_off;
+        char* b = Bs(buf) + st_off;
+        *reinterpret_cast<uint4*>(a) = ra0; *reinterpret_cast<uint4*>(a + 32 * 128) = ra1;
+        *reinterpret_cast<uint4*>(a + 64 * 128) = ra2; *reinterpret_cast<uint4*>(a + 96 * 128) = ra3;
+        *reinterpret_cast<uint4*>(b) = rb0; *reinterpret_cast<uint4*>(b + 32 * 128) = rb1;
+        *reinterpret_cast<uint4*>(b + 64 * 128) = rb2; *reinterpret_cast<uint4*>(b + 96 * 128) = rb3;
+        if (tid < F8_BM) Ss(buf)[tid] = rs_a * to_f(rs_w);
     };
 
     f32x4_q acc[4][4];

@@ -29,7 +29,7 @@ class Engine:
         self._keep = [embed, final_norm, lm_head, layers]  # keep the weights alive
         mc = _hip.ModelConfig(config["vocab_size"], config["hidden_size"], config["num_layers"], config["num_heads"],
                               config["num_kv_heads"], config["head_dim"], config["intermediate_size"], max_seq_len, max_batch,
-                              float(config["norm_eps"]), float(config["rope_theta"]), 1 if weight_format == "fp8" else 0,
+                              float(config["norm_eps"]), float(config["rope_theta"]), {"bf16": 0, "fp8": 1, "fp8a8": 2}[weight_format],
                               1 if use_qk_norm else 0)
         for a in (embed, final_norm):
             if a.dtype != bfloat16:

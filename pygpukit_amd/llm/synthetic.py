@@ -28,7 +28,7 @@ def engine_layer_arrays(lw: dict, weight_format: str = "bf16") -> dict:
     mats = {"w_qkv": np.concatenate([lw["q"], lw["k"], lw["v"]], axis=0), "w_o": lw["o"],
             "w_gate_up": np.concatenate([lw["gate"], lw["up"]], axis=0), "w_down": lw["down"]}
     for name, m in mats.items():
-        if weight_format == "fp8":
+        if weight_format in ("fp8", "fp8a8"):
             codes, scale = quantize_linear_fp8(np.ascontiguousarray(m, dtype=np.float32))
             out[name], out["s" + name[1:]] = codes, scale
         else:
@@ -95,3 +95,48 @@ QWEN3_0_6B = dict(vocab_size=151936, hidden_size=1024, num_layers=28, num_heads=
                   intermediate_size=3072, rope_theta=1e6, norm_eps=1e-6)
 LLAMA3_8B = dict(vocab_size=128256, hidden_size=4096, num_layers=32, num_heads=32, num_kv_heads=8, head_dim=128,
                  intermediate_size=14336, rope_theta=5e5, norm_eps=1e-5)
+
+
+def random_engine_weights(cfg: dict, seed: int = 0, *, std: float = 0.02, fp8: bool = False, keep_bf16: bool = True,
+                          use_qk_norm: bool = False, threads: int = 8) -> dict:
+    """Random-init weights in ENGINE layout for models too large to stage as fp32 on the host (Llama-3-8B shape):
+    each fused matrix (qkv, o, gate_up, down) is drawn N(0, std^2) from its own generator
+    (SeedSequence [seed, layer, index]), rounded to bf16, uploaded, and - with fp8=True - block-quantised ON THE
+    DEVICE by pgk_quantize_fp8_blocks.  Returns {"embed", "final_norm", "bf16": [layer dicts] | None,
+    "fp8": [layer dicts] | None}; the two layer lists describe the same model."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from pygpukit_amd.ops.matmul.fp8 import quantize_fp8_blocks
+
+    H, D, I, V = cfg["hidden_size"], cfg["head_dim"], cfg["intermediate_size"], cfg["vocab_size"]
+    Hq, Hkv = cfg["num_heads"], cfg["num_kv_heads"]
+    shapes = {"w_qkv": ((Hq + 2 * Hkv) * D, H), "w_o": (H, Hq * D), "w_gate_up": (2 * I, H), "w_down": (H, I)}
+
+    def draw(key, shape):
+        rng = np.random.default_rng(np.random.SeedSequence([seed, *key]))
+        w = rng.standard_normal(shape, dtype=np.float32)
+        w *= np.float32(std)
+        return f32_to_bf16_bits(w).reshape(shape)
+
+    ones_h, ones_d = _bf16(np.ones(H, np.float32)), _bf16(np.ones(D, np.float32))
+    out = {"embed": from_numpy(draw((1 << 20,), (V, H))), "final_norm": ones_h, "bf16": [] if keep_bf16 or not fp8 else None,
+           "fp8": [] if fp8 else None}
+    jobs = [(l, i, name) for l in range(cfg["num_layers"]) for i, name in enumerate(shapes)]
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        results = pool.map(lambda j: draw((j[0], j[1]), shapes[j[2]]), jobs)
+        cur16, cur8 = {}, {}
+        for (l, i, name), bits in zip(jobs, results):
+            dev = from_numpy(bits)
+            if out["bf16"] is not None:
+                cur16[name] = dev
+            if fp8:
+                cur8[name], cur8["s" + name[1:]] = quantize_fp8_blocks(dev)
+            if i == len(shapes) - 1:
+                norms = {"attn_norm": ones_h, "mlp_norm": ones_h, "q_norm": ones_d if use_qk_norm else None,
+                         "k_norm": ones_d if use_qk_norm else None}
+                if out["bf16"] is not None:
+                    out["bf16"].append({**cur16, **norms})
+                if fp8:
+                    out["fp8"].append({**cur8, **norms})
+                cur16, cur8 = {}, {}
+    return out

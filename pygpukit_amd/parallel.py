@@ -57,6 +57,22 @@ class ControlPlane:
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
         return float(t[0])
 
+    def min_over_ranks(self, value: float) -> float:
+        return -self.max_over_ranks(-float(value))
+
+    def first_note(self, note: str | None) -> str | None:
+        """The first non-empty string any rank holds (rank order) - used to report one rank's error on rank 0."""
+        if self._dist is None:
+            return note
+        outs = [None] * self.world
+        self._dist.all_gather_object(outs, note)
+        return next((o for o in outs if o), None)
+
+    def all_gather_array(self, local: np.ndarray) -> list[np.ndarray]:
+        """Equal-shape int32 arrays from every rank, over the control plane."""
+        flat = self.gather_int32(np.ascontiguousarray(local, dtype=np.int32).ravel())
+        return [f.reshape(local.shape) for f in flat]
+
     def sum_over_ranks(self, value: float) -> float:
         if self._dist is None:
             return float(value)
@@ -103,12 +119,18 @@ class RcclComm:
         self._hip = _hip
         self.cp = cp
         _hip.call("pgk_device_set", cp.local_rank)
-        uid = None
+        uid, err = None, None
         if cp.rank == 0:
-            buf = C.create_string_buffer(128)
-            _hip.call("pgk_comm_unique_id", buf)
-            uid = buf.raw
+            # a failure here must not skip the broadcast below (the other ranks are already waiting in it)
+            try:
+                buf = C.create_string_buffer(128)
+                _hip.call("pgk_comm_unique_id", buf)
+                uid = buf.raw
+            except Exception as e:  # noqa: BLE001
+                uid, err = bytes(128), e
         uid = cp.broadcast_bytes(uid, 128, 0)
+        if uid == bytes(128):
+            raise RuntimeError(f"RCCL unique id could not be created on rank 0: {err}")
         h = C.c_void_p()
         _hip.call("pgk_comm_init", C.byref(h), uid, cp.rank, cp.world)
         self._h = h.value

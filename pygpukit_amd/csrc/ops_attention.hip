@@ -268,12 +268,29 @@ static pgk_status launch_prefill(const T* q, const T* k, const T* v, T* out, int
     return PGK_OK;
 }
 
+pgk_status flash_prefill(const void* q, const void* k, const void* v, void* out, int hq, int hkv, int q_len, int kv_len, int d,
+                         float scale, long long qh, long long qs, long long kh, long long ks, long long oh, long long os,
+                         int dt16, hipStream_t st);
+
+// 0 = first-generation kernel only, 1 = second-generation (ops_flash.hip) whenever it applies; default: by size
+static int flash_gen_choice() {
+    static const int v = [] { const char* e = getenv("PGK_FLASH_GEN"); return e ? atoi(e) : -1; }();
+    return v;
+}
+
 template <class T>
 static pgk_status sdpa_dispatch(const void* q, const void* k, const void* v, void* out, int hq, int hkv, int q_len,
                                 int kv_len, int d, float scale, const AttnStrides& sd, hipStream_t st) {
     const bool mfma_ok = !std::is_same<T, float>::value && (d == 64 || d == 128) && aligned16(q) && aligned16(k) &&
                          aligned16(v) && sd.qs % 8 == 0 && sd.ks % 8 == 0 && sd.qh % 8 == 0 && sd.kh % 8 == 0;
     if constexpr (!std::is_same<T, float>::value) {
+        // second generation: 128-row query tiles, transposed-score orientation (ops_flash.hip); the first-generation
+        // kernel keeps the short prompts, where its 64-row tiles give twice the workgroups
+        const bool gen2_ok = mfma_ok && (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && sd.os % 4 == 0 && sd.oh % 4 == 0;
+        const int gen = flash_gen_choice();
+        if (gen2_ok && (gen == 1 || (gen < 0 && q_len > 128)))
+            return flash_prefill(q, k, v, out, hq, hkv, q_len, kv_len, d, scale, sd.qh, sd.qs, sd.kh, sd.ks, sd.oh, sd.os,
+                                 std::is_same<T, f16>::value ? 1 : 0, st);
         if (mfma_ok) {
             if (d == 128) return launch_prefill<T, 128>((const T*)q, (const T*)k, (const T*)v, (T*)out, hq, hkv, q_len, kv_len, scale, sd, st);
             return launch_prefill<T, 64>((const T*)q, (const T*)k, (const T*)v, (T*)out, hq, hkv, q_len, kv_len, scale, sd, st);

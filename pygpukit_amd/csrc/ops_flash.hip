@@ -1,0 +1,308 @@
+// Flash-attention prefill for gfx950 (bf16 / f16, head_dim 64 or 128), second generation.
+//
+// Orientation: the scores are computed TRANSPOSED, S^T[kv][q] = K . Q^T on v_mfma_f32_32x32x16, so a lane owns one
+// query column (q = lane & 31) and its 16 accumulator registers per 32-kv sub-tile are kv rows.  Consequences:
+//   * the online softmax (max, exp2, sum) of a query row is lane-local arithmetic over registers plus ONE exchange
+//     with lane ^ 32 (the other half of the rows) - no LDS, no 16-lane butterflies;
+//   * the probabilities are already laid out as the B operand of the second product O^T[d][q] += V^T[d][kv] . P^T[kv][q]:
+//     registers 8s..8s+7 of a sub-tile, packed pairwise to 16-bit, ARE the k-step-s fragment (k order permuted:
+//     element j of lane half h is kv = 16s + 8(j>>2) + 4h + (j&3)); the V^T operand is read in the same permuted
+//     order (two 8-byte LDS reads per fragment), so P never touches LDS;
+//   * alpha (the running-max rescale) and 1/l are per-lane scalars for the O^T accumulators (q is again the lane).
+// V arrives transposed: a small pre-pass writes V^T [Hkv][D][kv_pad] (zero padded to a multiple of 64 positions) so
+// that both LDS images are filled with 16-byte row-contiguous chunks.
+// Workgroup = 4 waves = 128 query rows of one head; KV tiles of 64 positions, K [64][D] and V^T [D][64] double
+// buffered in LDS (64 KiB at D = 128: two workgroups per CU); the global loads of tile t+1 are issued before the
+// MFMAs of tile t and written to the other buffer after them: one barrier per tile.
+// Workgroups are ordered heavy-first (causal: late query tiles see more keys) and all query heads of a kv head
+// share id % Hkv, i.e. an XCD when Hkv is a multiple of 8, so the K/V stream of a head is served by one L2.
+// Mask: kv_pos <= (kv_len - q_len) + q_pos  (reference: native/ops/nn/attention_kernels.cuh:32-148).
+
+#include <type_traits>
+
+#include "pgk_device.cuh"
+#include "pgk_internal.h"
+
+namespace pgk {
+
+typedef __bf16 bf16x8_fl __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_fl __attribute__((ext_vector_type(8)));
+typedef float f32x16_fl __attribute__((ext_vector_type(16)));
+
+template <class T> __device__ __forceinline__ f32x16_fl mfma32(const uint4& a, const uint4& b, f32x16_fl c);
+template <> __device__ __forceinline__ f32x16_fl mfma32<bf16>(const uint4& a, const uint4& b, f32x16_fl c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_fl, a), __builtin_bit_cast(bf16x8_fl, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16_fl mfma32<f16>(const uint4& a, const uint4& b, f32x16_fl c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_fl, a), __builtin_bit_cast(f16x8_fl, b), c, 0, 0, 0);
+}
+template <class T> __device__ __forceinline__ uint32_t pack16x2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack16x2<bf16>(float lo, float hi) { return pack_bf16x2(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack16x2<f16>(float lo, float hi) {
+    return (uint32_t)__builtin_bit_cast(uint16_t, static_cast<_Float16>(lo)) | ((uint32_t)__builtin_bit_cast(uint16_t, static_cast<_Float16>(hi)) << 16);
+}
+
+struct FlashStrides { long long qh, qs, kh, ks, oh, os; };
+
+constexpr int FL_BQ = 128, FL_BKV = 64, FL_THREADS = 256;
+
+// K image: [64 kv][D] 16-bit, 16-byte chunk c (0..D/8-1) of row r at r*2D + ((c ^ (r & (D/8-1))) << 4)
+template <int D> __device__ __forceinline__ int fl_k_off(int r, int c) { return r * (2 * D) + ((c ^ (r & (D / 8 - 1))) << 4); }
+// V^T image: [D][64 kv] 16-bit = 128-byte rows, 8-byte chunk c8 (0..15) of row d at d*128 + ((c8 ^ ((d>>1) & 15)) << 3):
+// the 32 rows a half-wave reads at one c8 then fall on 32 different bank pairs
+__device__ __forceinline__ int fl_v_off(int d, int c8) { return d * 128 + ((c8 ^ ((d >> 1) & 15)) << 3); }
+
+template <class T, int D>
+__global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, const T* k, const T* vt, T* out, int hq, int hkv,
+                                                              int q_len, int kv_len, int kv_pad, float scale_log2e, FlashStrides sd) {
+    constexpr int NC = D / 8;            // 16-byte chunks per K row
+    constexpr int KS = D / 16;           // k-steps of Q.K^T
+    constexpr int DT = D / 32;           // 32-row tiles of O^T
+    constexpr int KCH = 64 * NC / FL_THREADS;   // K chunks staged per thread
+    constexpr int VCH = D * 8 / FL_THREADS;     // V^T chunks staged per thread
+    constexpr int K_BYTES = 64 * D * 2, V_BYTES = D * 128;
+    extern __shared__ __attribute__((aligned(16))) char fl_smem[];   // K[2] | V^T[2]
+    auto Ks = [&](int buf) -> char* { return fl_smem + buf * K_BYTES; };
+    auto Vs = [&](int buf) -> char* { return fl_smem + 2 * K_BYTES + buf * V_BYTES; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, ql = lane & 31, h = lane >> 5;
+    // workgroup id -> (kv head, query head in its group, query tile), heavy tiles first
+    const int rep = hq / hkv, nqt = (q_len + FL_BQ - 1) / FL_BQ;
+    const int id = blockIdx.x;
+    const int kvh = id % hkv, rest = id / hkv;
+    const int head = kvh * rep + rest % rep;
+    const int qt = nqt - 1 - rest / rep;
+    const int qw0 = qt * FL_BQ + wid * 32;          // first query row of this wave
+    const int causal_off = kv_len - q_len;
+    const T* qh = q + (size_t)head * sd.qh;
+    const T* kh = k + (size_t)kvh * sd.kh;
+    const T* vh = vt + (size_t)kvh * D * kv_pad;
+
+    // Q^T fragments (B operand): lane = query column, k = d
+    uint4 qf[KS];
+    {
+        const T* qrow = qh + (size_t)min(qw0 + ql, q_len - 1) * sd.qs + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(qrow + ks * 16);
+    }
+    f32x16_fl o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;    // running max (scaled, log2 domain) and this lane's half of the row sum
+
+    const int q_last = min(qt * FL_BQ + FL_BQ - 1, q_len - 1);
+    const int kv_end = min(kv_len, causal_off + q_last + 1);
+    const int nt = (kv_end + FL_BKV - 1) / FL_BKV;
+
+    // staging in NAMED registers (an array here ends up in scratch memory at this register pressure, see
+    // ops_fp8_gemm.hip): chunk i of this thread is c = tid + 256 i; KCH = VCH = D / 32 chunks each
+    static_assert(KCH == VCH && (KCH == 2 || KCH == 4), "staging is written for D = 64 / 128");
+    uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
+    const int kr = tid / NC, kc16 = tid % NC;               // K: row kr + (256/NC) i, chunk kc16
+    constexpr int KR_STEP = FL_THREADS / NC;
+    const int vd = tid >> 3, vc = tid & 7;                  // V^T: row vd + 32 i, chunk vc
+    const T* vsrc = vh + (size_t)vd * kv_pad + vc * 8;
+    auto k_src = [&](int kv0, int i) { return kh + (size_t)min(kv0 + kr + KR_STEP * i, kv_len - 1) * sd.ks + kc16 * 8; };
+    auto load_tile = [&](int t) {
+        const int kv0 = t * FL_BKV;
+        rk0 = *reinterpret_cast<const uint4*>(k_src(kv0, 0));
+        rk1 = *reinterpret_cast<const uint4*>(k_src(kv0, 1));
+        if constexpr (KCH == 4) {
+            rk2 = *reinterpret_cast<const uint4*>(k_src(kv0, 2));
+            rk3 = *reinterpret_cast<const uint4*>(k_src(kv0, 3));
+        }
+        rv0 = *reinterpret_cast<const uint4*>(vsrc + kv0);
+        rv1 = *reinterpret_cast<const uint4*>(vsrc + (size_t)32 * kv_pad + kv0);
+        if constexpr (VCH == 4) {
+            rv2 = *reinterpret_cast<const uint4*>(vsrc + (size_t)64 * kv_pad + kv0);
+            rv3 = *reinterpret_cast<const uint4*>(vsrc + (size_t)96 * kv_pad + kv0);
+        }
+    };
+    auto put_v = [&](char* base, int d, const uint4& x) {
+        *reinterpret_cast<uint2*>(base + fl_v_off(d, 2 * vc)) = make_uint2(x.x, x.y);
+        *reinterpret_cast<uint2*>(base + fl_v_off(d, 2 * vc + 1)) = make_uint2(x.z, x.w);
+    };
+    auto store_tile = [&](int buf) {
+        char* kb = Ks(buf);
+        char* vb = Vs(buf);
+        *reinterpret_cast<uint4*>(kb + fl_k_off<D>(kr, kc16)) = rk0;
+        *reinterpret_cast<uint4*>(kb + fl_k_off<D>(kr + KR_STEP, kc16)) = rk1;
+        if constexpr (KCH == 4) {
+            *reinterpret_cast<uint4*>(kb + fl_k_off<D>(kr + 2 * KR_STEP, kc16)) = rk2;
+            *reinterpret_cast<uint4*>(kb + fl_k_off<D>(kr + 3 * KR_STEP, kc16)) = rk3;
+        }
+        put_v(vb, vd, rv0);
+        put_v(vb, vd + 32, rv1);
+        if constexpr (VCH == 4) {
+            put_v(vb, vd + 64, rv2);
+            put_v(vb, vd + 96, rv3);
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    // Retire the Q loads HERE: if they are still counted as pending at the loop header, hipcc's conservative
+    // vmcnt bookkeeping waits for them in every iteration - behind the tile prefetch issued at the top of the
+    // loop, i.e. it drains the prefetch before the first MFMA.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks].x), "v"(qf[ks].y), "v"(qf[ks].z), "v"(qf[ks].w));
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1, kv0 = t * FL_BKV;
+        if (t + 1 < nt) load_tile(t + 1);
+        // tiles entirely above this wave's diagonal contribute nothing (wave-uniform)
+        if (kv0 <= causal_off + qw0 + 31) {
+            // ---- S^T = K . Q^T : two 32-kv sub-tiles ----
+            f32x16_fl s0, s1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint4 a0 = *reinterpret_cast<const uint4*>(Ks(buf) + fl_k_off<D>(ql, 2 * ks + h));
+                const uint4 a1 = *reinterpret_cast<const uint4*>(Ks(buf) + fl_k_off<D>(32 + ql, 2 * ks + h));
+                s0 = mfma32<T>(a0, qf[ks], s0);
+                s1 = mfma32<T>(a1, qf[ks], s1);
+            }
+            // ---- scale, mask, online softmax (this lane: query qw0 + ql, kv rows (r&3) + 8(r>>2) + 4h of each sub-tile) ----
+            const bool need_mask = kv0 + FL_BKV - 1 > causal_off + qw0 || kv0 + FL_BKV > kv_len;   // wave-uniform
+            const int lim = min(causal_off + qw0 + ql, kv_len - 1) - kv0 - 4 * h;                  // local kv row <= lim is visible
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kvl = (r & 3) + 8 * (r >> 2);
+                float v0 = s0[r] * scale_log2e, v1 = s1[r] * scale_log2e;
+                if (need_mask) {
+                    v0 = kvl <= lim ? v0 : -INFINITY;
+                    v1 = 32 + kvl <= lim ? v1 : -INFINITY;
+                }
+                s0[r] = v0; s1[r] = v1;
+                mx = fmaxf(mx, fmaxf(v0, v1));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;        // a fully masked row so far: p = exp2(-inf) = 0
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);   // m_run = -inf -> 0 (accumulators are 0 anyway)
+            float ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_use);
+                s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_use);
+                ls += s0[r] + s1[r];
+            }
+            l_run = l_run * alpha + ls;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            // ---- O^T += V^T . P^T : 4 k-steps of 16 kv ----
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                uint4 pb;
+                if (s < 2) {
+                    pb = make_uint4(pack16x2<T>(s0[8 * s + 0], s0[8 * s + 1]), pack16x2<T>(s0[8 * s + 2], s0[8 * s + 3]),
+                                    pack16x2<T>(s0[8 * s + 4], s0[8 * s + 5]), pack16x2<T>(s0[8 * s + 6], s0[8 * s + 7]));
+                } else {
+                    pb = make_uint4(pack16x2<T>(s1[8 * (s - 2) + 0], s1[8 * (s - 2) + 1]), pack16x2<T>(s1[8 * (s - 2) + 2], s1[8 * (s - 2) + 3]),
+                                    pack16x2<T>(s1[8 * (s - 2) + 4], s1[8 * (s - 2) + 5]), pack16x2<T>(s1[8 * (s - 2) + 6], s1[8 * (s - 2) + 7]));
+                }
+#pragma unroll
+                for (int i = 0; i < DT; ++i) {
+                    const int d = i * 32 + ql;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(Vs(buf) + fl_v_off(d, 4 * s + h));
+                    const uint2 hi = *reinterpret_cast<const uint2*>(Vs(buf) + fl_v_off(d, 4 * s + 2 + h));
+                    o[i] = mfma32<T>(make_uint4(lo.x, lo.y, hi.x, hi.y), pb, o[i]);
+                }
+            }
+        }
+        if (t + 1 < nt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane = query row, registers 4g..4g+3 of tile i are d = 32i + 8g + 4h .. +3 ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    const int qrow = qw0 + ql;
+    if (qrow < q_len) {
+        T* orow = out + (size_t)head * sd.oh + (size_t)qrow * sd.os;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 w;
+                w.x = pack16x2<T>(o[i][4 * g] * inv, o[i][4 * g + 1] * inv);
+                w.y = pack16x2<T>(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + i * 32 + 8 * g + 4 * h) = w;
+            }
+    }
+}
+
+// V [Hkv][kv][D] (element strides kh, ks) -> V^T [Hkv][D][kv_pad], zero beyond kv_len.  One workgroup per
+// (64-position tile, kv head); the tile goes through LDS so both sides move 16-byte chunks.
+template <class T, int D>
+__global__ __launch_bounds__(256) void transpose_v_kernel(const T* v, T* vt, int kv_len, int kv_pad, long long kh, long long ks) {
+    __shared__ uint16_t tile[64][D + 2];
+    const int kv0 = blockIdx.x * 64, head = blockIdx.y;
+    const T* vh = v + (size_t)head * kh;
+    constexpr int NC = D / 8;
+    for (int c = threadIdx.x; c < 64 * NC; c += 256) {
+        const int r = c / NC, kc = c % NC;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (kv0 + r < kv_len) x = *reinterpret_cast<const uint4*>(vh + (size_t)(kv0 + r) * ks + kc * 8);
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tile[r][kc * 8 + 2 * j] = (uint16_t)(w[j] & 0xFFFFu);
+            tile[r][kc * 8 + 2 * j + 1] = (uint16_t)(w[j] >> 16);
+        }
+    }
+    __syncthreads();
+    T* oh = vt + (size_t)head * D * kv_pad;
+    for (int c = threadIdx.x; c < D * 8; c += 256) {
+        const int d = c >> 3, kc = c & 7;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (uint32_t)tile[kc * 8 + 2 * j][d] | ((uint32_t)tile[kc * 8 + 2 * j + 1][d] << 16);
+        *reinterpret_cast<uint4*>(oh + (size_t)d * kv_pad + kv0 + kc * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+template <class T, int D>
+static pgk_status flash_launch(const T* q, const T* k, const T* v, T* out, int hq, int hkv, int q_len, int kv_len, float scale,
+                               const FlashStrides& sd, hipStream_t st) {
+    const int kv_pad = ceil_div(kv_len, 64) * 64;
+    void* vt = nullptr;
+    if (pgk_status r = pgk_malloc(&vt, (size_t)hkv * D * kv_pad * sizeof(T))) return r;
+    transpose_v_kernel<T, D><<<dim3(kv_pad / 64, hkv), 256, 0, st>>>(v, (T*)vt, kv_len, kv_pad, sd.kh, sd.ks);
+    constexpr size_t LDS = 2 * (size_t)(64 * D * 2) + 2 * (size_t)(D * 128);
+    static bool attr_done = false;
+    if (LDS > 48 * 1024 && !attr_done) {
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_kernel<T, D>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        attr_done = true;
+    }
+    const int nqt = ceil_div(q_len, FL_BQ);
+    flash_fwd_kernel<T, D><<<nqt * hq, FL_THREADS, LDS, st>>>(q, k, (const T*)vt, out, hq, hkv, q_len, kv_len, kv_pad,
+                                                             scale * 1.4426950408889634f, sd);
+    const hipError_t e = hipGetLastError();
+    pgk_free(vt);   // stream-ordered reuse: later work on this stream runs after the kernels above
+    PGK_CHECK_HIP(e);
+    return PGK_OK;
+}
+
+// entry used by ops_attention.hip's dispatcher; dt16: 0 = bf16, 1 = f16
+pgk_status flash_prefill(const void* q, const void* k, const void* v, void* out, int hq, int hkv, int q_len, int kv_len, int d,
+                         float scale, long long qh, long long qs, long long kh, long long ks, long long oh, long long os,
+                         int dt16, hipStream_t st) {
+    const FlashStrides sd{qh, qs, kh, ks, oh, os};
+    if (dt16 == 0) {
+        if (d == 128) return flash_launch<bf16, 128>((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, hq, hkv, q_len, kv_len, scale, sd, st);
+        return flash_launch<bf16, 64>((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, hq, hkv, q_len, kv_len, scale, sd, st);
+    }
+    if (d == 128) return flash_launch<f16, 128>((const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, hq, hkv, q_len, kv_len, scale, sd, st);
+    return flash_launch<f16, 64>((const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, hq, hkv, q_len, kv_len, scale, sd, st);
+}
+
+}  // namespace pgk

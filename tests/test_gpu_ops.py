@@ -448,7 +448,10 @@ def test_sdpa_golden_fp32(tag):
 
 @pytest.mark.parametrize("dt", ["bfloat16", "float16"])
 @pytest.mark.parametrize("cfg", [(4, 4, 9, 9, 128), (4, 2, 3, 11, 64), (16, 8, 128, 128, 128), (8, 2, 70, 200, 128),
-                                 (2, 2, 130, 130, 64), (4, 1, 1, 37, 128)])
+                                 (2, 2, 130, 130, 64), (4, 1, 1, 37, 128),
+                                 # q_len > 128: the transposed-score kernel (ops_flash.hip), incl. ragged tiles and kv offset
+                                 (4, 2, 129, 129, 128), (8, 2, 300, 300, 128), (2, 1, 257, 400, 128), (4, 4, 513, 513, 64),
+                                 (2, 2, 200, 1000, 64)])
 def test_sdpa_flash_prefill(dt, cfg):
     hq, hkv, ql, kl, d = cfg
     rng = np.random.default_rng(10)
@@ -461,15 +464,41 @@ def test_sdpa_flash_prefill(dt, cfg):
     assert np.abs(o - ref).max() < 5e-2  # reference's FA2-vs-SDPA bar (benchmarks/test_flash_attention.py:169)
 
 
-def test_sdpa_softmax_max_jump():
+@pytest.mark.parametrize("ql", [128, 192])   # 128: first-generation kernel, 192: transposed-score kernel
+def test_sdpa_softmax_max_jump(ql):
     """Force the online-softmax rescale: one key far above the rest late in the sequence."""
     rng = np.random.default_rng(11)
-    hq, ql, d = 2, 192, 128
+    hq, d = 2, 128
     q, k, v = (rng.standard_normal((hq, ql, d)).astype(np.float32) for _ in range(3))
-    k[:, 150] = q[:, 160] * 3.0  # huge score for queries >= 150 at kv tile 2
+    k[:, ql - 42] = q[:, ql - 32] * 3.0  # huge score for late queries, in the last kv tile
     ref = O.sdpa_causal(O.bf16_round(q), O.bf16_round(k), O.bf16_round(v))
     o = host(ops.sdpa_causal(dev(q, "bfloat16"), dev(k, "bfloat16"), dev(v, "bfloat16")))
     close(o, ref, "bfloat16")
+
+
+def test_sdpa_flash_long_sequence_properties():
+    """S = 2048 (BASELINE config-5 scale per head is 4096): size-independent checks of the long path -
+    row 0 attends to key 0 only (out == V[0]); constant V is returned unchanged (softmax weights sum to 1);
+    and a strided sample of rows matches the oracle computed for those rows alone."""
+    rng = np.random.default_rng(15)
+    hq, hkv, S, d = 4, 2, 2048, 128
+    q, k = rng.standard_normal((hq, S, d)).astype(np.float32), rng.standard_normal((hkv, S, d)).astype(np.float32)
+    v = rng.standard_normal((hkv, S, d)).astype(np.float32)
+    qd, kd = dev(q, "bfloat16"), dev(k, "bfloat16")
+    o = host(ops.sdpa_causal(qd, kd, dev(v, "bfloat16")))
+    vr = O.bf16_round(v)
+    np.testing.assert_array_equal(o[:, 0], np.repeat(vr[:, 0], hq // hkv, axis=0))
+    oc = host(ops.sdpa_causal(qd, kd, dev(np.full_like(v, 0.75), "bfloat16")))
+    np.testing.assert_allclose(oc, 0.75, atol=4e-3)
+    rows = np.array([1, 63, 64, 127, 128, 1000, 1023, 1024, 2047])
+    qr, kr = O.bf16_round(q), O.bf16_round(k)
+    for h in range(hq):
+        kh, vh = kr[h // (hq // hkv)], vr[h // (hq // hkv)]
+        sc = (qr[h, rows] @ kh.T) / np.sqrt(d)
+        sc[np.arange(S)[None, :] > rows[:, None]] = -np.inf
+        p = np.exp(sc - sc.max(axis=1, keepdims=True))
+        ref = (p / p.sum(axis=1, keepdims=True)) @ vh
+        assert rel_err(o[h, rows], ref) < 1e-2
 
 
 @pytest.mark.parametrize("dt", ["bfloat16", "float32"])

@@ -19,6 +19,16 @@ namespace pgk {
 template <class T> pgk_status launch_gemv(const T*, const T*, const T*, T*, int, int, int, hipStream_t);
 pgk_status wsgemm_nt(const bf16* a, int lda, const void* w, const bf16* wscale, bool fp8, void* c, const bf16* bias, int mode,
                      int splits, int M, int N, int K, hipStream_t st);
+pgk_status gemm256_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, bool accum_f32, int M, int N, int K,
+                           hipStream_t st);
+// the 256 x 256 structure needs enough tiles to fill the chip and whole 128-byte K rows
+static bool use_gemm256(int M, int N, int K) {
+    const char* e = getenv("PGK_GEMM256");   // read per call: tests flip it to drive small shapes through both kernels
+    const int force = e ? atoi(e) : -1;
+    if (force == 0 || K % 64 != 0) return false;
+    if (force == 1) return true;
+    return (long long)ceil_div(M, 256) * ceil_div(N, 256) >= 192;
+}
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -346,6 +356,7 @@ pgk_status engine_gemm_nt(const bf16* A, const void* W, const bf16* wscale, bool
         if (accum_f32) return dispatch_mfma<bf16, B_NT_FP8, 1>(A, W, wscale, nullptr, C, M, N, K, st);
         return dispatch_mfma<bf16, B_NT_FP8, 0>(A, W, wscale, nullptr, C, M, N, K, st);
     }
+    if (use_gemm256(M, N, K)) return gemm256_bf16_nt(A, (const bf16*)W, nullptr, C, accum_f32, M, N, K, st);
     if (accum_f32) return dispatch_mfma<bf16, B_NT, 1>(A, W, nullptr, nullptr, C, M, N, K, st);
     return dispatch_mfma<bf16, B_NT, 0>(A, W, nullptr, nullptr, C, M, N, K, st);
 }
@@ -378,6 +389,8 @@ pgk_status pgk_gemm_nt(const void* a, const void* w, const void* bias, void* c, 
     }
     if (dt == PGK_BF16 && m <= 128)   // weight-bound regime: stream W once through the skinny MFMA kernel
         return wsgemm_nt((const bf16*)a, k, w, nullptr, false, c, (const bf16*)bias, 0, 1, m, n, k, st);
+    if (dt == PGK_BF16 && use_gemm256(m, n, k))
+        return gemm256_bf16_nt((const bf16*)a, (const bf16*)w, (const bf16*)bias, c, false, m, n, k, st);
     if (dt == PGK_BF16) return dispatch_mfma<bf16, B_NT>((const bf16*)a, w, nullptr, (const bf16*)bias, (bf16*)c, m, n, k, st);
     return dispatch_mfma<f16, B_NT>((const f16*)a, w, nullptr, (const f16*)bias, (f16*)c, m, n, k, st);
 }

@@ -1,0 +1,180 @@
+// Large-tile MFMA GEMMs for gfx950 (prefill at S >= 256):  C[M,N] = A[M,K] . W[N,K]^T
+//
+//   bf16:  A, W bf16, fp32 accumulate, bf16 C or fp32 "+=" (the engine's residual stream)
+//   fp8 :  A, W OCP e4m3 with 128-wide block scales (see ops_fp8_gemm.hip for the contract), same outputs
+//
+// Structure: 256 x 256 output tile per workgroup, 8 waves as 2 (M) x 4 (N), 128 x 64 per wave = 8 x 4 MFMA tiles of
+// 16 x 16 held in 128 accumulator registers; K tiles of 128 BYTES per row (64 bf16 / 128 fp8).  Both operand
+// tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass), 16 bytes
+// per lane, one wave-instruction = 8 rows x 128 B written linearly; the bank swizzle is applied on the SOURCE
+// address (lane p of a row fetches chunk p ^ (row & 7)) and again on the fragment reads, so the LDS image is the
+// XOR-swizzled one without a scatter.  Two LDS buffers (128 KiB): the DMA of tile t+1 is issued before the MFMAs
+// of tile t; one counted wait + one raw barrier per K tile.  All LDS lives in ONE dynamic array (a second
+// __shared__ object makes hipcc wait vmcnt(0) before every fragment read).
+// Workgroup ids are remapped so that the tiles an XCD works on form a compact patch of the output (shared A / W
+// panels stay in that XCD's L2).
+//
+// The reference calls CUTLASS / cuBLASLt here (native/ops/matmul/matmul.cu:142-235); nothing of theirs is used.
+
+#include "gemv_core.cuh"
+#include "pgk_internal.h"
+
+namespace pgk {
+
+typedef __bf16 bf16x8_g __attribute__((ext_vector_type(8)));
+typedef float f32x4_g __attribute__((ext_vector_type(4)));
+typedef int i32x8_g __attribute__((ext_vector_type(8)));
+
+constexpr int G2_BM = 256, G2_BN = 256, G2_THREADS = 512;
+constexpr int G2_TILE = 256 * 128;   // bytes of one operand tile
+
+// byte offset of 16-byte chunk c (0..7) of row r in a [rows][128 B] tile
+__device__ __forceinline__ int g2_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 bytes from per-lane global addresses to LDS [lds_addr, +1024).
+// Written as inline asm on purpose: issued through __builtin_amdgcn_global_load_lds, hipcc (ROCm 7.2) puts an
+// s_waitcnt vmcnt(0) in front of the next ds_read of the kernel - it cannot tell the buffer being filled from the
+// buffer being read - and the prefetch is drained the moment it is issued.  The waits that order these DMAs
+// before the fragment reads are the explicit vmcnt + barrier pairs in the kernels below.
+__device__ __forceinline__ void g2_dma16(const void* src, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ uint32_t g2_lds_addr(const char* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+// workgroup id -> output tile: ids are dealt round-robin to the 8 XCDs, so XCD x owns ids x, x+8, ...; give it a
+// contiguous run of tiles, and walk the tiles in groups of 4 tile-rows so a run is a compact patch.
+__device__ __forceinline__ void g2_tile_of(int id, int nwg, int ntm, int ntn, int& tm, int& tn) {
+    const int q = nwg / 8, r = nwg % 8, xcd = id % 8, idx = id / 8;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective for any nwg
+    constexpr int GM = 4;
+    const int per_group = GM * ntn, g = t / per_group, first = g * GM;
+    const int gsz = min(ntm - first, GM), in = t % per_group;
+    tm = first + in % gsz;
+    tn = in / gsz;
+}
+
+template <int EPI>   // 0: bf16 C store (+bias); 1: fp32 C +=
+__global__ __launch_bounds__(G2_THREADS) void gemm256_bf16_kernel(const bf16* A, const bf16* W, const bf16* bias, void* Cv,
+                                                                   int M, int N, int K, int ntm, int ntn) {
+    extern __shared__ __attribute__((aligned(16))) char g2_smem[];   // A[2] | W[2]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 2, wc = wid & 3, q = lane >> 4, l15 = lane & 15;
+    int tm, tn;
+    g2_tile_of(blockIdx.x, ntm * ntn, ntm, ntn, tm, tn);
+    const int m0 = tm * G2_BM, n0 = tn * G2_BN;
+
+    // DMA sources: wave w moves rows 32w .. 32w+31 of each tile, 8 rows per instruction; lane -> (row l>>3, chunk p = l&7)
+    const int drow = wid * 32 + (lane >> 3);
+    const int dchunk = (lane & 7) ^ (lane >> 3);            // logical chunk that lands at linear position l&7
+    const bf16* a_src[4];
+    const bf16* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_src[i] = A + (size_t)min(m0 + drow + 8 * i, M - 1) * K + dchunk * 8;
+        w_src[i] = W + (size_t)min(n0 + drow + 8 * i, N - 1) * K + dchunk * 8;
+    }
+    const uint32_t lds0 = g2_lds_addr(g2_smem);
+    auto stage = [&](int kt, int buf) {
+        const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G2_TILE + wid * 4096);
+        const uint32_t w_dst = __builtin_amdgcn_readfirstlane(lds0 + (2 + buf) * G2_TILE + wid * 4096);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            g2_dma16(a_src[i] + (size_t)kt * 64, a_dst + i * 1024);
+            g2_dma16(w_src[i] + (size_t)kt * 64, w_dst + i * 1024);
+        }
+    };
+
+    f32x4_g acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_g{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row = base + l15 (base a multiple of 16), chunk = ks*4 + q
+    const int f_off0 = l15 * 128 + (((0 + q) ^ (l15 & 7)) << 4);
+    const int f_off1 = l15 * 128 + (((4 + q) ^ (l15 & 7)) << 4);
+    const int a_base = wr * 128 * 128, w_base = wc * 64 * 128;
+
+    const int nk = K / 64;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        const char* As = g2_smem + buf * G2_TILE + a_base;
+        const char* Ws = g2_smem + (2 + buf) * G2_TILE + w_base;
+        // Both k-steps' fragments are requested before the first MFMA: the second set's LDS latency runs under the
+        // first 32 MFMAs (one wave cannot rely on its SIMD neighbour for that).  The sched_barriers pin this order;
+        // left alone, hipcc keeps only two reads in flight and waits for one before every group of 4 MFMAs.
+        uint4 fa0[8], fb0[4], fa1[8], fb1[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa0[i] = *reinterpret_cast<const uint4*>(As + i * 2048 + f_off0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb0[j] = *reinterpret_cast<const uint4*>(Ws + j * 2048 + f_off0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa1[i] = *reinterpret_cast<const uint4*>(As + i * 2048 + f_off1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb1[j] = *reinterpret_cast<const uint4*>(Ws + j * 2048 + f_off1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_g, fa0[i]),
+                                                                    __builtin_bit_cast(bf16x8_g, fb0[j]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_g, fa1[i]),
+                                                                    __builtin_bit_cast(bf16x8_g, fb1[j]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // C/D map: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wc * 64 + j * 16 + l15;
+        if (col >= N) continue;
+        float b = 0.f;
+        if constexpr (EPI == 0) b = bias ? to_f(bias[col]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wr * 128 + i * 16 + q * 4 + r;
+                if (row >= M) continue;
+                if constexpr (EPI == 0) reinterpret_cast<bf16*>(Cv)[(size_t)row * N + col] = from_f<bf16>(acc[i][j][r] + b);
+                else reinterpret_cast<float*>(Cv)[(size_t)row * N + col] += acc[i][j][r];
+            }
+    }
+}
+
+// bf16 NT on the 256^2 structure; caller guarantees K % 64 == 0 and 16-byte aligned rows
+pgk_status gemm256_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, bool accum_f32, int M, int N, int K,
+                           hipStream_t st) {
+    PGK_REQUIRE(K % 64 == 0 && K >= 64, "gemm256: K=%d must be a multiple of 64", K);
+    constexpr size_t LDS = 4 * (size_t)G2_TILE;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_bf16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        attr_done = true;
+    }
+    const int ntm = ceil_div(M, G2_BM), ntn = ceil_div(N, G2_BN);
+    if (accum_f32) gemm256_bf16_kernel<1><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn);
+    else gemm256_bf16_kernel<0><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn);
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
+}
+
+}  // namespace pgk

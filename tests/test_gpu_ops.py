@@ -356,6 +356,38 @@ def test_w8a16_gemm_kn(m):
     assert rel_err(c[:8], c2) < 1e-2
 
 
+# ----------------------------------------------------------------------------- 256 x 256 LDS-DMA GEMM
+@pytest.mark.parametrize("shape", [(256, 256, 64), (512, 768, 256), (300, 520, 192), (1000, 260, 1024)])
+def test_gemm256_bf16_matches_oracle_and_128_tile_kernel(shape, monkeypatch):
+    """The large-tile kernel (LDS-DMA staging, source-side swizzle) against the oracle, on shapes with ragged M / N
+    edges and several K tiles; the 128-tile kernel on the same inputs must agree to bf16 rounding of the same sums."""
+    M, N, K = shape
+    rng = np.random.default_rng(31)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    w[:, 0] += np.arange(N) % 7 * 0.01       # asymmetric: a transposed store cannot pass
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = O.bf16_round(a) @ O.bf16_round(w).T + O.bf16_round(bias)
+    ad, wd, bd = dev(a, "bfloat16"), dev(w, "bfloat16"), dev(bias, "bfloat16")
+    monkeypatch.setenv("PGK_GEMM256", "1")
+    c256 = host(ops.matmul_nt(ad, wd, bd))
+    monkeypatch.setenv("PGK_GEMM256", "0")
+    c128 = host(ops.matmul_nt(ad, wd, bd))
+    assert rel_err(c256, ref) < 1e-2 and rel_err(c128, ref) < 1e-2
+    assert rel_err(c256, c128) < 3e-3
+
+
+def test_gemm256_exact_integers(monkeypatch):
+    """Small integers are exact in bf16 and fp32: the two kernels and the oracle must agree bit for bit."""
+    rng = np.random.default_rng(32)
+    M, N, K = 512, 512, 128
+    a = rng.integers(-3, 4, (M, K)).astype(np.float32)
+    w = rng.integers(-3, 4, (N, K)).astype(np.float32)
+    monkeypatch.setenv("PGK_GEMM256", "1")
+    c = host(ops.matmul_nt(dev(a, "bfloat16"), dev(w, "bfloat16")))
+    np.testing.assert_array_equal(c, O.bf16_round(a @ w.T))
+
+
 # ----------------------------------------------------------------------------- fp8 x fp8 GEMM
 def _fp8_vals(codes):
     return O.fp8_e4m3_table()[codes]

@@ -14,7 +14,7 @@ for i in range(0, len(a), 4):
     q, k, v = dev(bf((S, hq, D))), dev(bf((hkv, S, D))), dev(bf((hkv, S, D)))
     o = C.c_void_p(); _hip.call("pgk_malloc", C.byref(o), S * hq * D * 2)
     # q/out in the projection's [S, H, D] layout, K/V in the cache layout [Hkv, S, D]
-    run = lambda: _hip.call("pgk_sdpa_causal", q, k, v, o, hq, hkv, S, S, D, C.c_float(0.0), D, hq * D, S * D, D, D, hq * D, 2, None)
+    run = lambda: _hip.call("pgk_sdpa_causal", q, k, v, o, hq, hkv, S, S, D, C.c_float(0.0), D, hq * D, S * D, D, D, hq * D, 3, None)
     e0, e1 = C.c_void_p(), C.c_void_p()
     _hip.call("pgk_event_create", C.byref(e0)); _hip.call("pgk_event_create", C.byref(e1))
     for _ in range(3): run()

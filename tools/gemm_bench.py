@@ -4,7 +4,7 @@ import ctypes as C, sys, numpy as np
 sys.path.insert(0, '.')
 from pygpukit_amd import _hip
 
-PGK_BF16 = 2
+PGK_BF16 = 3
 
 
 def dev(nbytes, fill=None):

@@ -159,6 +159,143 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_bf16_kernel(const bf16* A,
     }
 }
 
+// ---- fp8 x fp8 with 128-wide block scales on the same structure --------------------------------------------
+// K tile = 128 fp8 = one scale block: per tile the 256 row scales of A (fp32) and the two weight-block scales of
+// the tile's 256 columns (bf16) are DMA'd into a small LDS array next to the operand tiles - every global load
+// in the loop is an LDS-DMA, so no compiler-counted vmcnt ever drains the prefetch.  One v_mfma_f32_16x16x128_f8f6f4
+// per 16x16 output tile and K tile, issued on a zero accumulator and folded in with the scale product.
+__device__ __forceinline__ void g2_dma4(const void* src, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ void g2_dma2(const void* src, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+}
+
+constexpr int G2_SCALE_BYTES = 256 * 4 + 256;   // per buffer: 256 fp32 row scales | 64 lanes x 4 B of weight-scale slots (2 used)
+
+template <int EPI>   // 0: bf16 C store; 1: fp32 C +=
+__global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* A, const float* sa, const uint8_t* W, const bf16* sw,
+                                                                  void* Cv, int M, int N, int K, int ntm, int ntn) {
+    extern __shared__ __attribute__((aligned(16))) char g2_smem[];   // A[2] | W[2] | scales[2]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 2, wc = wid & 3, q = lane >> 4, l15 = lane & 15;
+    int tm, tn;
+    g2_tile_of(blockIdx.x, ntm * ntn, ntm, ntn, tm, tn);
+    const int m0 = tm * G2_BM, n0 = tn * G2_BN;
+    const int KB = K >> 7, NB = (N + 127) >> 7;
+
+    const int drow = wid * 32 + (lane >> 3);
+    const int dchunk = (lane & 7) ^ (lane >> 3);
+    const uint8_t* a_src[4];
+    const uint8_t* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_src[i] = A + (size_t)min(m0 + drow + 8 * i, M - 1) * K + dchunk * 16;
+        w_src[i] = W + (size_t)min(n0 + drow + 8 * i, N - 1) * K + dchunk * 16;
+    }
+    // scale DMAs: waves 0-3 fetch 64 row scales each; wave 4 fetches the (up to) two weight-block scales
+    const float* sa_src = sa + (size_t)min(m0 + (wid & 3) * 64 + lane, M - 1) * KB;
+    const bf16* sw_src = sw + (size_t)min(2 * tn + (lane & 1), NB - 1) * KB;
+    const uint32_t lds0 = g2_lds_addr(g2_smem);
+    auto stage = [&](int kt, int buf) {
+        const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G2_TILE + wid * 4096);
+        const uint32_t w_dst = __builtin_amdgcn_readfirstlane(lds0 + (2 + buf) * G2_TILE + wid * 4096);
+        const uint32_t s_dst = __builtin_amdgcn_readfirstlane(lds0 + 4 * G2_TILE + buf * G2_SCALE_BYTES + (wid < 4 ? wid * 256 : 1024));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            g2_dma16(a_src[i] + (size_t)kt * 128, a_dst + i * 1024);
+            g2_dma16(w_src[i] + (size_t)kt * 128, w_dst + i * 1024);
+        }
+        if (wid < 4) g2_dma4(sa_src + kt, s_dst);
+        else if (wid == 4) g2_dma2(sw_src + kt, s_dst);
+    };
+
+    f32x4_g acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_g{0.f, 0.f, 0.f, 0.f};
+
+    // fragment reads: row = base + l15, the lane's 32 bytes are chunks 2q and 2q+1
+    const int f_lo = l15 * 128 + (((2 * q) ^ (l15 & 7)) << 4);
+    const int f_hi = l15 * 128 + (((2 * q + 1) ^ (l15 & 7)) << 4);
+    const int a_base = wr * 128 * 128, w_base = wc * 64 * 128;
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < KB; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KB) stage(kt + 1, buf ^ 1);
+        const char* As = g2_smem + buf * G2_TILE + a_base;
+        const char* Ws = g2_smem + (2 + buf) * G2_TILE + w_base;
+        const char* Ss = g2_smem + 4 * G2_TILE + buf * G2_SCALE_BYTES;
+        i32x8_g fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint4 lo = *reinterpret_cast<const uint4*>(Ws + j * 2048 + f_lo), hi = *reinterpret_cast<const uint4*>(Ws + j * 2048 + f_hi);
+            fb[j] = i32x8_g{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        }
+        // (a sub-dword LDS-DMA still strides the lanes by 4 bytes: lane l's 16 bits land at +4l, zero-extended)
+        const float swv = to_f(*reinterpret_cast<const bf16*>(Ss + 1024 + (wc >> 1) * 4));   // this wave's 64 columns lie in one block
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            i32x8_g fa[4];
+            f32x4_g sc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int off = (half * 4 + i) * 2048;
+                const uint4 lo = *reinterpret_cast<const uint4*>(As + off + f_lo), hi = *reinterpret_cast<const uint4*>(As + off + f_hi);
+                fa[i] = i32x8_g{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+                sc[i] = *reinterpret_cast<const f32x4_g*>(Ss + (wr * 128 + (half * 4 + i) * 16 + q * 4) * 4) * swv;
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4_g t = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], f32x4_g{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
+                    acc[half * 4 + i][j] += t * sc[i];
+                }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wc * 64 + j * 16 + l15;
+        if (col >= N) continue;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wr * 128 + i * 16 + q * 4 + r;
+                if (row >= M) continue;
+                if constexpr (EPI == 0) reinterpret_cast<bf16*>(Cv)[(size_t)row * N + col] = from_f<bf16>(acc[i][j][r]);
+                else reinterpret_cast<float*>(Cv)[(size_t)row * N + col] += acc[i][j][r];
+            }
+    }
+}
+
+pgk_status gemm256_fp8_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, void* c, bool accum_f32, int M, int N,
+                          int K, hipStream_t st) {
+    PGK_REQUIRE(K % 128 == 0 && K >= 128, "gemm256 fp8: K=%d must be a multiple of 128", K);
+    constexpr size_t LDS = 4 * (size_t)G2_TILE + 2 * G2_SCALE_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_fp8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_fp8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        attr_done = true;
+    }
+    const int ntm = ceil_div(M, G2_BM), ntn = ceil_div(N, G2_BN);
+    if (accum_f32) gemm256_fp8_kernel<1><<<ntm * ntn, G2_THREADS, LDS, st>>>(a, sa, w, sw, c, M, N, K, ntm, ntn);
+    else gemm256_fp8_kernel<0><<<ntm * ntn, G2_THREADS, LDS, st>>>(a, sa, w, sw, c, M, N, K, ntm, ntn);
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
+}
+
 // bf16 NT on the 256^2 structure; caller guarantees K % 64 == 0 and 16-byte aligned rows
 pgk_status gemm256_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, bool accum_f32, int M, int N, int K,
                            hipStream_t st) {

@@ -5,6 +5,8 @@ fp8 <= 5e-2; copies and index ops bit-exact."""
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import pytest
 
@@ -441,6 +443,30 @@ def test_gemm_fp8_blockwise(shape):
     assert rel_err(c, a @ w.T) < 5e-2
 
 
+@pytest.mark.parametrize("shape", [(256, 256, 128), (300, 520, 384), (1000, 260, 1024)])
+def test_gemm256_fp8_matches_oracle_and_128_tile_kernel(shape, monkeypatch):
+    """fp8 x fp8 on the 256-tile LDS-DMA structure (operand tiles AND scales arrive by DMA) vs the oracle and vs the
+    128-tile kernel, on ragged M / N (N = 260, 520: a last 128-column scale block that is only partly there)."""
+    M, N, K = shape
+    rng = np.random.default_rng(33)
+    a = (rng.standard_normal((M, K)) * rng.uniform(0.1, 4.0, (M, 1))).astype(np.float32)
+    w = (rng.standard_normal((N, K)) * 0.02 * rng.uniform(0.5, 2.0, (N, 1))).astype(np.float32)
+    a8, sa = O.quantize_fp8_rows(a)
+    npad = (N + 127) // 128 * 128
+    wp = np.zeros((npad, K), np.float32)
+    wp[:N] = w
+    w8, sw = O.quantize_fp8_e4m3_block(wp)
+    w8 = np.ascontiguousarray(w8[:N])
+    ref = O.gemm_fp8_blockwise(a8, sa, w8, sw)
+    args = [from_numpy(a8), from_numpy(w8), from_numpy(sa), from_numpy(sw)]
+    monkeypatch.setenv("PGK_GEMM256", "1")
+    c256 = host(ops.gemm_fp8_fp8_blockwise_nt(*args))
+    monkeypatch.setenv("PGK_GEMM256", "0")
+    c128 = host(ops.gemm_fp8_fp8_blockwise_nt(*args))
+    assert rel_err(c256, ref) < 3e-3 and rel_err(c128, ref) < 3e-3
+    assert rel_err(c256, c128) < 3e-3
+
+
 def test_gemm_fp8_exact_integers_and_asymmetric_operand():
     """Small-integer operands with unit scales are exact in e4m3 and in fp32: the result must be bit-exact, which
     pins the A/B lane->k pairing and the C row/col map (an asymmetric W catches a transposed store)."""
@@ -455,8 +481,13 @@ def test_gemm_fp8_exact_integers_and_asymmetric_operand():
     a8, w8 = enc(ai), enc(wi)
     sa = np.ones((M, K // 128), np.float32)
     sw = np.full((2, K // 128), 0x3F80, np.uint16)
-    c = host(ops.gemm_fp8_fp8_blockwise_nt(from_numpy(a8), from_numpy(w8), from_numpy(sa), from_numpy(sw)))
-    np.testing.assert_array_equal(c, O.bf16_round(ai @ wi.T))
+    for force in ("0", "1"):      # 128-tile kernel, then the 256-tile LDS-DMA kernel
+        os.environ["PGK_GEMM256"] = force
+        try:
+            c = host(ops.gemm_fp8_fp8_blockwise_nt(from_numpy(a8), from_numpy(w8), from_numpy(sa), from_numpy(sw)))
+        finally:
+            del os.environ["PGK_GEMM256"]
+        np.testing.assert_array_equal(c, O.bf16_round(ai @ wi.T))
 
 
 def test_matmul_fp8_auto_quantise():

@@ -97,6 +97,8 @@ def main() -> None:
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-decode-tokens", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--long-prefill", type=int, default=2048,
+                    help="also time a prefill of this many tokens (the MFMA-bound regime); 0 = skip")
     ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (result is then INVALID)")
     args = ap.parse_args()
 
@@ -241,6 +243,32 @@ def main() -> None:
         all_tokens = tokens[None]
     gather_s = time.perf_counter() - t0
 
+    # ---- long prefill: the regime where the projections are MFMA-bound (S = 128 above is weight/latency-bound) ----
+    long_pf = None
+    if args.long_prefill > 0 and cp.rank == 0:
+        from pygpukit_amd.llm.engine import Engine
+
+        SL = args.long_prefill
+        eng_l = Engine(cfg, eng._keep[0], eng._keep[3], eng._keep[1], None, max_seq_len=SL + 8, max_batch=1,
+                       weight_format=args.weight_format)   # same device weights, its own KV cache
+        lp = [int(t) for t in np.random.default_rng(2000 + args.seed).integers(0, cfg["vocab_size"], SL)]
+        eng_l.prefill(lp, want_last_logits=False)
+        l_ms = []
+        for _ in range(3):
+            _hip.call("pgk_event_record", start_ev, None)
+            eng_l.prefill(lp, want_last_logits=False)
+            _hip.call("pgk_event_record", stop_ev, None)
+            _hip.call("pgk_event_sync", stop_ev)
+            ms = _hip.C.c_float()
+            _hip.call("pgk_event_elapsed_ms", start_ev, stop_ev, _hip.C.byref(ms))
+            l_ms.append(ms.value)
+        lf = prefill_flops(cfg, SL, all_rows=False)
+        lmed = float(np.median(l_ms))
+        long_pf = {"tokens": SL, "ms": lmed, "tflops": lf / (lmed * 1e-3) / 1e12, "flops": lf, "logits": "last row only",
+                   "frac_mfma_peak": lf / (lmed * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "tokens_per_s": SL / (lmed * 1e-3),
+                   "runs_ms": [round(x, 3) for x in l_ms]}
+        del eng_l
+
     # ---- per-kernel timing (eager, event after every kernel) for the roofline objects ----
     prof = eng.profile_step(B, 8)
     ctx_mid = P + W + K // 2
@@ -281,6 +309,7 @@ def main() -> None:
         "roofline": roofline, "step_roofline": step_roofline,
         "prefill": {"ms": pf_med, "tflops": pf_flops / (pf_med * 1e-3) / 1e12, "flops": pf_flops, "logits": "last row only",
                     "frac_mfma_peak": pf_flops / (pf_med * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "runs_ms": [round(x, 3) for x in pf_ms]},
+        "prefill_long": long_pf,
         "first_tokens": [int(t) for t in tokens[: min(8, len(tokens)), 0]],
         "setup_s": time.perf_counter() - t_setup,
     }

@@ -192,6 +192,14 @@ pgk_status pgk_kv_cache_write(const void* new_kv, void* cache, int seq, int hkv,
  * out_idx: device int32[rows]. */
 pgk_status pgk_argmax(const void* x, int rows, int n, pgk_dtype dt, int32_t* out_idx, pgk_stream s);
 
+/* sample_multinomial / sample_topk / sample_topp / sample_topk_to_buf_ptr (src/pygpukit/ops/sampling.py:11-141,
+ * native/ops/sampling/sampling.cu): one token per logits row, temperature > 0, top_k = 0 disables top-k,
+ * top_p = 1 disables the nucleus; the uniform random number comes from `u` or, when `u_buf` is non-NULL, from device
+ * memory (graph-replay compatible).  Deterministic function of its inputs, defined in csrc/ops_sampling.hip and
+ * restated by oracle/cpu_ref.py sample_token_u.  Result: int32 per row in device memory. */
+pgk_status pgk_sample_token(const void* logits, int rows, int vocab, pgk_dtype dt, float temperature, int top_k,
+                            float top_p, float u, const float* u_buf, int32_t* out_tokens, pgk_stream s);
+
 /* ---------------------------------------------------------------------- matmul ------ */
 /* ops.cuh:119-124 matmul: C[M,N] = A[M,K] B[K,N]  (row-major, fp32 accumulate, dt out). */
 pgk_status pgk_gemm_nn(const void* a, const void* b, void* c, int m, int n, int k, pgk_dtype dt, pgk_stream s);

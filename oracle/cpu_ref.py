@@ -296,6 +296,40 @@ def sample_token(logits: np.ndarray, temperature: float = 1.0, top_k: int = 0, t
     return int(rng.choice(len(probs), p=probs))
 
 
+def sample_token_u(logits: np.ndarray, temperature: float, top_k: int, top_p: float, u: float, return_margin: bool = False):
+    """[build-defined; semantics of the reference's HOST sampler src/pygpukit/llm/sampling.py:12-63 (top-k, then a true
+    nucleus, then the draw) made a deterministic function of the uniform number u, with the inverse-CDF walk in
+    ascending index order of native/ops/sampling/sampling_kernels.cuh:255-268.  The reference's device top-k / top-p
+    kernels are racy / approximate (sampling_kernels.cuh:419-497, 640-680) and cannot serve as a specification.]
+    Integer masses floor(exp(z - max) * 2^32) make every sum exact; restated by csrc/ops_sampling.hip.
+    return_margin: also return how far (relative to the kept mass) u * total is from the nearest decision boundary."""
+    z = (np.asarray(logits, dtype=np.float32) / np.float32(temperature)).astype(np.float32)
+    V = z.size
+    q = np.floor(np.exp(z - z.max()).astype(np.float32).astype(np.float64) * 4294967296.0).astype(np.uint64)
+    order = np.lexsort((np.arange(V), -z.astype(np.float64)))      # z descending, index ascending among ties
+    kept = np.ones(V, bool)
+    if 0 < top_k < V:
+        kept[:] = False
+        kept[order[:top_k]] = True
+    if top_p < 1.0:
+        o = order[kept[order]]
+        cum = np.cumsum(q[o].astype(np.float64))                    # < 2^53: exact
+        target = max(float(np.ceil(np.float64(np.float32(top_p)) * cum[-1])), 1.0)
+        n = int(np.searchsorted(cum, target, side="left")) + 1
+        kept[:] = False
+        kept[o[:n]] = True
+    idx = np.nonzero(kept)[0]
+    cum = np.cumsum(q[idx].astype(np.float64))
+    thr = np.float64(np.float32(u)) * cum[-1]
+    pos = int(np.searchsorted(cum, thr, side="left"))
+    pos = min(pos, idx.size - 1)
+    tok = int(idx[pos])
+    if return_margin:
+        below = cum[pos - 1] if pos > 0 else -np.inf
+        return tok, float(min(cum[pos] - thr, thr - below) / cum[-1])
+    return tok
+
+
 def argmax_lowest_index(logits: np.ndarray) -> int:
     """Greedy token: np.argmax semantics (lowest index among ties), which is what the
     reference's host sampler applies (src/pygpukit/llm/sampling.py:60-61)."""

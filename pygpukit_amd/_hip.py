@@ -81,6 +81,7 @@ _PROTOS = {
     "pgk_w8a16_gemm_kn": [_V, _V, _V, _V, _I, _I, _I, _V], "pgk_w8a16_gemm_nk": [_V, _V, _V, _V, _I, _I, _I, _V],
     "pgk_gemm_fp8_nt": [_V, _V, _V, _V, _V, _I, _I, _I, _V], "pgk_quantize_fp8_rows": [_V, _V, _V, _I, _I, _I, _V],
     "pgk_quantize_fp8_blocks": [_V, _V, _V, _I, _I, _V],
+    "pgk_sample_token": [_V, _I, _I, _I, _F, _I, _F, _F, _V, _V, _V],
     "pgk_sdpa_causal": [_V, _V, _V, _V, _I, _I, _I, _I, _I, _F, _I64, _I64, _I64, _I64, _I64, _I64, _I, _V],
     "pgk_sdpa_fixed_cache": [_V, _V, _V, _V, _I, _I, _I, _I, _I, _F, _I, _V, _V, _I, _V],
     "pgk_engine_create": [C.POINTER(ModelConfig), _V, _V, _V, C.POINTER(LayerWeights), c_void_pp],

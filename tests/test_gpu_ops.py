@@ -596,6 +596,83 @@ def test_sdpa_fixed_cache_multi_query():
         ops.sdpa_causal_fixed_cache(dev(q, "bfloat16"), dev(kc, "bfloat16"), dev(vc, "bfloat16"), out, max_seq + 1)
 
 
+# ----------------------------------------------------------------------------- device sampling
+def _safe_us(lg, T, k, p, rng, n=6):
+    """u values whose decision is at least 1e-4 of the kept mass away from a boundary (expf vs np.exp differ by ulps)."""
+    us = []
+    while len(us) < n:
+        u = float(np.float32(rng.random()))
+        _, margin = O.sample_token_u(lg, T, k, p, u, return_margin=True)
+        if margin > 1e-4:
+            us.append(u)
+    return us
+
+
+@pytest.mark.parametrize("dt", ["float32", "bfloat16", "float16"])
+@pytest.mark.parametrize("params", [(1.0, 0, 1.0), (0.7, 40, 1.0), (1.3, 0, 0.9), (0.8, 50, 0.95), (1.0, 1, 1.0), (2.0, 1000, 0.5)])
+def test_sample_token_gpu_matches_oracle(dt, params):
+    """Index-exact against the oracle's restatement for given u (multinomial, top-k, nucleus, both), on a peaked
+    LLM-like row of Qwen3's vocabulary size."""
+    T, k, p = params
+    rng = np.random.default_rng(41)
+    V = 151936
+    lg = rounded((rng.standard_normal(V) * 2.5).astype(np.float32), dt)
+    lg[rng.integers(0, V, 20)] += rounded(rng.uniform(4, 9, 20).astype(np.float32), dt)
+    lg = rounded(lg, dt)
+    d = dev(lg, dt)
+    for u in _safe_us(lg, T, k, p, rng) + [0.0]:
+        assert ops.sample_token_gpu(d, T, k, p, u=u) == O.sample_token_u(lg, T, k, p, u)
+
+
+def test_sample_ties_and_small_vocab():
+    """Ties at the top-k / nucleus boundary are kept lowest-index-first; tiny rows (V < threads) work."""
+    lg = np.array([1.0, 3.0, 3.0, 3.0, 0.5, 3.0, -2.0], np.float32)
+    d = dev(lg)
+    for k, p in ((2, 1.0), (3, 1.0), (0, 0.5), (0, 0.3), (4, 0.6)):
+        for u in (0.0, 0.2, 0.45, 0.7, 0.99):
+            _, margin = O.sample_token_u(lg, 1.0, k, p, u, return_margin=True)
+            if margin > 1e-4:
+                assert ops.sample_token_gpu(d, 1.0, k, p, u=u) == O.sample_token_u(lg, 1.0, k, p, u), (k, p, u)
+    assert ops.sample_topk(d, 1, 1.0, u=0.77) == 1          # top-1 == lowest-index maximum
+    assert ops.sample_token_gpu(d, 0.0) == 1                # temperature 0 -> greedy
+
+
+def test_sample_distribution_and_seed():
+    """With the host generator seeded, draws are reproducible and follow softmax(logits / T) restricted to top-k."""
+    lg = np.array([2.0, 1.0, 0.0, -1.0, 3.0, 0.5], np.float32)
+    d = dev(lg)
+    ops.set_sampling_seed(7)
+    a = [ops.sample_topk(d, 3, 1.0) for _ in range(400)]
+    ops.set_sampling_seed(7)
+    b = [ops.sample_topk(d, 3, 1.0) for _ in range(400)]
+    assert a == b and set(a) <= {0, 1, 4}
+    pr = np.exp(lg[[0, 1, 4]])
+    pr /= pr.sum()
+    freq = np.array([a.count(0), a.count(1), a.count(4)]) / 400
+    assert np.abs(freq - pr).max() < 0.08
+
+
+def test_sample_topk_to_buf_ptr_in_graph():
+    """The random number is read from device memory at replay time: one captured launch, different u -> different tokens."""
+    rng = np.random.default_rng(42)
+    lg = (rng.standard_normal((2, 5000)) * 3).astype(np.float32)
+    d = dev(lg, "float16")
+    res, ub = pk.empty((2,), "int32"), from_numpy(np.array([0.0], np.float32))
+    graph = pk.CudaGraph()
+    graph.begin_capture()
+    ops.sample_topk_to_buf_ptr(d, res, ub, 20, 0.9)
+    graph.end_capture()
+    lgr = rounded(lg, "float16")
+    for u in (0.1, 0.5, 0.93):
+        ub.copy_from_numpy(np.array([u], np.float32))
+        graph.replay()
+        graph.synchronize()
+        got = res.to_numpy()
+        for r in range(2):
+            tok, margin = O.sample_token_u(lgr[r], 0.9, 20, 1.0, u, return_margin=True)
+            assert margin < 1e-4 or got[r] == tok
+
+
 # ----------------------------------------------------------------------------- graph
 def test_graph_capture_replay_reads_device_scalars():
     """Capture embedding_lookup_ptr + rmsnorm once; replay with a different token id in the device buffer."""

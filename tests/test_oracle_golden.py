@@ -196,3 +196,29 @@ def test_fp8_row_quantiser_round_trip_and_gemm_identity():
     wc, ws = O.quantize_fp8_e4m3_block(w)
     out = O.gemm_fp8_blockwise(codes, scale, wc, ws)
     np.testing.assert_allclose(out, deq.reshape(5, 256)[:, :128] * (O.fp8_e4m3_table()[wc][0, 0] * O.bf16_bits_to_f32(ws)[0, 0]), rtol=1e-6)
+
+
+def test_sample_token_u_restates_host_sampler_sets():
+    """The kept sets of sample_token_u are those of the reference-restating host sampler (sample_token): every token it
+    can return under top-k / top-p has non-zero probability there, u = 0 returns the lowest kept index, and the draw
+    frequencies follow the restricted softmax."""
+    rng = np.random.default_rng(5)
+    lg = (rng.standard_normal(300) * 2).astype(np.float32)
+    for k, p in ((0, 1.0), (10, 1.0), (0, 0.8), (25, 0.9)):
+        z = lg / np.float32(0.9)
+        probs = np.exp(z - z.max())
+        probs /= probs.sum()
+        if 0 < k < len(probs):
+            keep = np.argsort(probs)[-k:]
+            m = np.zeros_like(probs, bool); m[keep] = True
+            probs = np.where(m, probs, 0.0); probs /= probs.sum()
+        if p < 1.0:
+            si = np.argsort(probs)[::-1]
+            cut = min(np.searchsorted(np.cumsum(probs[si]), p) + 1, len(probs))
+            m = np.zeros_like(probs, bool); m[si[:cut]] = True
+            probs = np.where(m, probs, 0.0); probs /= probs.sum()
+        toks = [O.sample_token_u(lg, 0.9, k, p, float(u)) for u in rng.random(3000)]
+        assert all(probs[t] > 0 for t in toks)
+        assert O.sample_token_u(lg, 0.9, k, p, 0.0) == int(np.nonzero(probs)[0][0])
+        freq = np.bincount(toks, minlength=300) / 3000
+        assert np.abs(freq - probs).max() < 0.04

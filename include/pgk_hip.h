@@ -200,6 +200,32 @@ pgk_status pgk_argmax(const void* x, int rows, int n, pgk_dtype dt, int32_t* out
 pgk_status pgk_sample_token(const void* logits, int rows, int vocab, pgk_dtype dt, float temperature, int top_k,
                             float top_p, float u, const float* u_buf, int32_t* out_tokens, pgk_stream s);
 
+/* ------------------------------------------------- paged KV cache / continuous batching ------ */
+/* ops.cuh:466-478 paged_attention_v1 (native/ops/attention/paged_attention.cuh:46-200): single-query attention over a
+ * paged cache.  Q/out [num_seqs, Hq, D]; K/V cache [num_blocks, Hkv, block_size, D]; block_tables [num_seqs,
+ * max_blocks_per_seq] int32; context_lens [num_seqs] int32 (device).  scale <= 0 -> 1/sqrt(D).  max_context bounds the
+ * context lengths (it sizes the KV split); contexts beyond 512 need `workspace` of
+ * pgk_paged_attention_workspace_bytes bytes.  dt = PGK_BF16 / PGK_F16 (the reference is f16-only). */
+size_t pgk_paged_attention_workspace_bytes(int num_seqs, int num_heads, int head_dim, int max_context);
+pgk_status pgk_paged_attention_v1(const void* q, const void* k_cache, const void* v_cache, const int32_t* block_tables,
+                                  const int32_t* context_lens, void* out, int num_seqs, int num_heads, int num_kv_heads,
+                                  int head_dim, int block_size, int max_blocks_per_seq, int max_context, float scale,
+                                  void* workspace, pgk_dtype dt, pgk_stream s);
+/* ops.cuh:480-502 copy_to_paged_cache / reshape_and_cache (paged_attention.cuh:206-283): K_new/V_new
+ * [n_tokens, Hkv, D] rows scattered to slot_mapping[token] = physical_block * block_size + offset (negative: skip). */
+pgk_status pgk_paged_cache_write(const void* k_new, const void* v_new, void* k_cache, void* v_cache,
+                                 const int32_t* slot_mapping, int n_tokens, int num_kv_heads, int block_size, int head_dim,
+                                 int itemsize, pgk_stream s);
+/* ops.cuh:520-528 scatter_last_token_logits (continuous_batching.cuh:103-133): out[b] = logits[seq_start[b] + seq_lens[b] - 1] */
+pgk_status pgk_scatter_last_token_logits(const void* logits, void* out, const int32_t* seq_start, const int32_t* seq_lens,
+                                         int batch, int vocab, int itemsize, pgk_stream s);
+/* ops.cuh:530-539 prepare_position_ids (continuous_batching.cuh:139-165) */
+pgk_status pgk_prepare_position_ids(const int32_t* seq_start, const int32_t* seq_ctx, const int32_t* is_prefill,
+                                    const int32_t* input_lens, int32_t* position_ids, int batch, pgk_stream s);
+/* ops.cuh:550-553 check_eos (continuous_batching.cuh:231-241), :555-556 compute_cumsum (exclusive) */
+pgk_status pgk_check_eos(const int32_t* tokens, int32_t* finished, int n, int eos_token_id, pgk_stream s);
+pgk_status pgk_exclusive_cumsum_i32(const int32_t* in, int32_t* out, int n, pgk_stream s);
+
 /* ---------------------------------------------------------------------- matmul ------ */
 /* ops.cuh:119-124 matmul: C[M,N] = A[M,K] B[K,N]  (row-major, fp32 accumulate, dt out). */
 pgk_status pgk_gemm_nn(const void* a, const void* b, void* c, int m, int n, int k, pgk_dtype dt, pgk_stream s);

@@ -233,6 +233,47 @@ def split_qkv_batch(qkv, q_dim, k_dim, v_dim):
 # ---------------------------------------------------------------------------
 
 
+def paged_attention_v1(q, k_cache, v_cache, block_tables, context_lens, scale: float = 0.0):
+    """native/ops/attention/paged_attention.cuh:46-200: per (sequence, head) softmax(q . K^T * scale) . V over the first
+    context_len rows reached through the block table; GQA by kv_head = head // (Hq // Hkv).
+    q [num_seqs, Hq, D]; caches [num_blocks, Hkv, block_size, D]; returns fp32 [num_seqs, Hq, D]."""
+    num_seqs, hq, d = q.shape
+    _, hkv, bs, _ = k_cache.shape
+    if scale <= 0:
+        scale = 1.0 / np.sqrt(d)
+    out = np.zeros((num_seqs, hq, d), np.float32)
+    for sidx in range(num_seqs):
+        ctx = int(context_lens[sidx])
+        pages = [int(b) for b in block_tables[sidx, :(ctx + bs - 1) // bs]]
+        for h in range(hq):
+            kvh = h // (hq // hkv)
+            k = np.concatenate([k_cache[b, kvh] for b in pages], axis=0)[:ctx].astype(np.float64)
+            v = np.concatenate([v_cache[b, kvh] for b in pages], axis=0)[:ctx].astype(np.float64)
+            sc = (k @ q[sidx, h].astype(np.float64)) * scale
+            p = np.exp(sc - sc.max())
+            out[sidx, h] = ((p / p.sum()) @ v).astype(np.float32)
+    return out
+
+
+def paged_cache_write(k_new, v_new, k_cache, v_cache, slot_mapping):
+    """paged_attention.cuh:206-283 (copy_to_paged_cache / reshape_and_cache): row t goes to block slot//bs, offset slot%bs."""
+    bs = k_cache.shape[2]
+    for t, slot in enumerate(slot_mapping):
+        if slot < 0:
+            continue
+        k_cache[slot // bs, :, slot % bs, :] = k_new[t]
+        v_cache[slot // bs, :, slot % bs, :] = v_new[t]
+
+
+def prepare_position_ids(seq_start, seq_ctx, is_prefill, input_lens, total_tokens):
+    """native/ops/batch/continuous_batching.cuh:139-165."""
+    pos = np.zeros(total_tokens, np.int32)
+    for b in range(len(seq_start)):
+        for i in range(int(input_lens[b])):
+            pos[seq_start[b] + i] = i if is_prefill[b] else seq_ctx[b]
+    return pos
+
+
 def embedding_lookup(embed: np.ndarray, token_id: int) -> np.ndarray:
     """native/ops/nn/embedding_kernels.cuh:27-66: out[0,:] = embed[token_id,:]."""
     return embed[token_id : token_id + 1].copy()

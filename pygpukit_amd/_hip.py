@@ -81,6 +81,10 @@ _PROTOS = {
     "pgk_w8a16_gemm_kn": [_V, _V, _V, _V, _I, _I, _I, _V], "pgk_w8a16_gemm_nk": [_V, _V, _V, _V, _I, _I, _I, _V],
     "pgk_gemm_fp8_nt": [_V, _V, _V, _V, _V, _I, _I, _I, _V], "pgk_quantize_fp8_rows": [_V, _V, _V, _I, _I, _I, _V],
     "pgk_quantize_fp8_blocks": [_V, _V, _V, _I, _I, _V],
+    "pgk_paged_attention_v1": [_V, _V, _V, _V, _V, _V, _I, _I, _I, _I, _I, _I, _I, _F, _V, _I, _V],
+    "pgk_paged_cache_write": [_V, _V, _V, _V, _V, _I, _I, _I, _I, _I, _V],
+    "pgk_scatter_last_token_logits": [_V, _V, _V, _V, _I, _I, _I, _V], "pgk_prepare_position_ids": [_V, _V, _V, _V, _V, _I, _V],
+    "pgk_check_eos": [_V, _V, _I, _I, _V], "pgk_exclusive_cumsum_i32": [_V, _V, _I, _V],
     "pgk_sample_token": [_V, _I, _I, _I, _F, _I, _F, _F, _V, _V, _V],
     "pgk_sdpa_causal": [_V, _V, _V, _V, _I, _I, _I, _I, _I, _F, _I64, _I64, _I64, _I64, _I64, _I64, _I, _V],
     "pgk_sdpa_fixed_cache": [_V, _V, _V, _V, _I, _I, _I, _I, _I, _F, _I, _V, _V, _I, _V],
@@ -98,7 +102,8 @@ _PROTOS = {
     "pgk_comm_all_reduce_max_f64": [_V, _V, _I, _V], "pgk_comm_barrier": [_V, _V],
 }
 _NON_STATUS = {"pgk_last_error": ([], C.c_char_p), "pgk_version": ([], C.c_char_p),
-               "pgk_sdpa_decode_workspace_bytes": ([_I, _I, _I], C.c_size_t)}
+               "pgk_sdpa_decode_workspace_bytes": ([_I, _I, _I], C.c_size_t),
+               "pgk_paged_attention_workspace_bytes": ([_I, _I, _I, _I], C.c_size_t)}
 
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + list(_NON_STATUS))
 

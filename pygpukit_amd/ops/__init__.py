@@ -11,6 +11,9 @@ from pygpukit_amd.ops.nn import (bias_add_inplace, geglu, gelu, glu_packed, laye
                                 rope_inplace_f32table, sdpa_causal, sdpa_causal_fixed_cache, sdpa_causal_fixed_cache_ptr,
                                 sdpa_causal_strided, sigmoid, silu, slice_rows_range_ptr, split_qkv_batch, swiglu, tanh)
 from pygpukit_amd.ops.reduction import argmax, argmax_rows
+from pygpukit_amd.ops.paged import (allocate_kv_cache, argmax_sample, check_eos, compute_cumsum, copy_to_paged_cache, gather_embeddings,
+                                    paged_attention_v1, prepare_batch_inputs, prepare_position_ids, reshape_and_cache,
+                                    scatter_last_token_logits)
 from pygpukit_amd.ops.sampling import (sample_greedy, sample_multinomial, sample_token_gpu, sample_topk, sample_topk_to_buf_ptr,
                                        sample_topp, set_sampling_seed)
 from pygpukit_amd.ops.tensor import (cast_bf16_to_f32, cast_f16_to_f32, cast_f32_to_bf16, cast_f32_to_f16, concat_axis0,

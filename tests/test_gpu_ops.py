@@ -596,6 +596,92 @@ def test_sdpa_fixed_cache_multi_query():
         ops.sdpa_causal_fixed_cache(dev(q, "bfloat16"), dev(kc, "bfloat16"), dev(vc, "bfloat16"), out, max_seq + 1)
 
 
+# ----------------------------------------------------------------------------- paged KV cache / continuous batching
+def _paged_setup(rng, num_seqs, hkv, bs, d, ctxs, dt, num_blocks=None):
+    max_blocks = max((c + bs - 1) // bs for c in ctxs) + 1
+    num_blocks = num_blocks or num_seqs * max_blocks + 3
+    perm = rng.permutation(num_blocks)                      # scattered physical pages
+    tables = np.zeros((num_seqs, max_blocks), np.int32)
+    nxt = 0
+    for s_ in range(num_seqs):
+        for b in range((ctxs[s_] + bs - 1) // bs):
+            tables[s_, b] = perm[nxt]
+            nxt += 1
+    kc = rounded(rng.standard_normal((num_blocks, hkv, bs, d)).astype(np.float32), dt)
+    vc = rounded(rng.standard_normal((num_blocks, hkv, bs, d)).astype(np.float32), dt)
+    return tables, kc, vc
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("cfg", [(3, 16, 8, 128, 16, [37, 1, 160]), (2, 8, 8, 64, 8, [17, 64]), (1, 4, 1, 128, 32, [700]),
+                                 (2, 16, 2, 128, 16, [2048, 1300]), (5, 2, 2, 64, 4, [3, 9, 1, 12, 7])])
+def test_paged_attention_v1(dt, cfg):
+    """Split-KV flash-decoding over scattered pages vs the oracle; long contexts exercise the multi-slice merge, the
+    last page of every sequence is partial, and unused table entries point at page 0 (never read)."""
+    num_seqs, hq, hkv, d, bs, ctxs = cfg
+    rng = np.random.default_rng(51)
+    tables, kc, vc = _paged_setup(rng, num_seqs, hkv, bs, d, ctxs, dt)
+    q = rounded(rng.standard_normal((num_seqs, hq, d)).astype(np.float32), dt)
+    ref = O.paged_attention_v1(q, kc, vc, tables, np.array(ctxs, np.int32))
+    o = host(ops.paged_attention_v1(dev(q, dt), dev(kc, dt), dev(vc, dt), from_numpy(tables), from_numpy(np.array(ctxs, np.int32)),
+                                    max_context=max(ctxs)))
+    close(o, ref, dt)
+    assert np.abs(o - ref).max() < 1e-2
+
+
+def test_paged_cache_write_and_attention_round_trip():
+    """reshape_and_cache a prefill, copy_to_paged_cache one decode row, then attend: equals attention over the dense rows."""
+    rng = np.random.default_rng(52)
+    hq, hkv, d, bs, n = 8, 4, 128, 16, 45
+    num_blocks = 8
+    k = O.bf16_round(rng.standard_normal((n + 1, hkv, d)).astype(np.float32))
+    v = O.bf16_round(rng.standard_normal((n + 1, hkv, d)).astype(np.float32))
+    pages = [5, 2, 7]
+    slots = np.array([pages[t // bs] * bs + t % bs for t in range(n + 1)], np.int32)
+    kc, vc = ops.allocate_kv_cache(num_blocks, hkv, bs, d, bfloat16), ops.allocate_kv_cache(num_blocks, hkv, bs, d, bfloat16)
+    slot_pf = slots[:n].copy()
+    slot_pf[10] = -1                                      # a padding token: skipped
+    ops.reshape_and_cache(dev(k[:n], "bfloat16"), dev(v[:n], "bfloat16"), kc, vc, from_numpy(slot_pf))
+    ops.copy_to_paged_cache(dev(k[n:], "bfloat16"), dev(v[n:], "bfloat16"), kc, vc, from_numpy(slots[n:]))
+    rk, rv = np.zeros((num_blocks, hkv, bs, d), np.float32), np.zeros((num_blocks, hkv, bs, d), np.float32)
+    O.paged_cache_write(k[:n], v[:n], rk, rv, slot_pf)
+    O.paged_cache_write(k[n:], v[n:], rk, rv, slots[n:])
+    np.testing.assert_array_equal(host(kc), rk)
+    np.testing.assert_array_equal(host(vc), rv)
+    q = O.bf16_round(rng.standard_normal((1, hq, d)).astype(np.float32))
+    tables = np.array([pages + [0]], np.int32)
+    o = host(ops.paged_attention_v1(dev(q, "bfloat16"), kc, vc, from_numpy(tables), from_numpy(np.array([n + 1], np.int32))))
+    kd, vd = k.copy(), v.copy()
+    kd[10], vd[10] = 0, 0                                 # the skipped slot stayed zero
+    dense = O.sdpa_causal_fixed_cache(q.transpose(1, 0, 2), np.repeat(kd.transpose(1, 0, 2), hq // hkv, axis=0),
+                                      np.repeat(vd.transpose(1, 0, 2), hq // hkv, axis=0), n + 1)
+    close(o[0], dense[:, 0], "bfloat16")
+
+
+def test_continuous_batching_helpers():
+    rng = np.random.default_rng(53)
+    lists = [[5, 9, 2], [7], [1, 1, 4, 8, 3]]
+    ids, total = ops.prepare_batch_inputs(lists)
+    assert total == 9 and ids.to_numpy().tolist() == [5, 9, 2, 7, 1, 1, 4, 8, 3]
+    lens = from_numpy(np.array([3, 1, 5], np.int32))
+    starts = ops.compute_cumsum(lens)
+    assert starts.to_numpy().tolist() == [0, 3, 4]
+    E = rng.standard_normal((12, 64)).astype(np.float32)
+    g = ops.gather_embeddings(ids, dev(E, "bfloat16"), total)
+    np.testing.assert_array_equal(host(g), O.bf16_round(E)[ids.to_numpy()])
+    ctx = from_numpy(np.array([0, 17, 0], np.int32))
+    pf = from_numpy(np.array([1, 0, 1], np.int32))
+    pos = ops.prepare_position_ids(starts, ctx, pf, lens, 3, total)
+    np.testing.assert_array_equal(pos.to_numpy(), O.prepare_position_ids([0, 3, 4], [0, 17, 0], [1, 0, 1], [3, 1, 5], total))
+    logits = rng.standard_normal((total, 1000)).astype(np.float32)
+    last = ops.scatter_last_token_logits(dev(logits, "float16"), starts, lens, 3, 1000)
+    np.testing.assert_array_equal(host(last), rounded(logits, "float16")[[2, 3, 8]])
+    toks = ops.argmax_sample(last, 3, 1000)
+    np.testing.assert_array_equal(toks.to_numpy(), np.argmax(rounded(logits, "float16")[[2, 3, 8]], axis=1))
+    fin = ops.check_eos(toks, int(toks.to_numpy()[1]))
+    assert fin.to_numpy()[1] == 1 and fin.to_numpy().sum() >= 1
+
+
 # ----------------------------------------------------------------------------- device sampling
 def _safe_us(lg, T, k, p, rng, n=6):
     """u values whose decision is at least 1e-4 of the kept mass away from a boundary (expf vs np.exp differ by ulps)."""

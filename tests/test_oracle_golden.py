@@ -222,3 +222,18 @@ def test_sample_token_u_restates_host_sampler_sets():
         assert O.sample_token_u(lg, 0.9, k, p, 0.0) == int(np.nonzero(probs)[0][0])
         freq = np.bincount(toks, minlength=300) / 3000
         assert np.abs(freq - probs).max() < 0.04
+
+
+def test_paged_attention_oracle_equals_dense_fixed_cache():
+    """The paged restatement gathers the same rows the golden-pinned dense fixed-cache attention reads."""
+    rng = np.random.default_rng(8)
+    hq, hkv, d, bs, ctx = 4, 2, 32, 8, 21
+    k, v = rng.standard_normal((ctx, hkv, d)).astype(np.float32), rng.standard_normal((ctx, hkv, d)).astype(np.float32)
+    kc, vc = np.zeros((6, hkv, bs, d), np.float32), np.zeros((6, hkv, bs, d), np.float32)
+    pages = [4, 1, 3]
+    O.paged_cache_write(k, v, kc, vc, [pages[t // bs] * bs + t % bs for t in range(ctx)])
+    q = rng.standard_normal((1, hq, d)).astype(np.float32)
+    got = O.paged_attention_v1(q, kc, vc, np.array([pages], np.int32), [ctx])
+    dense = O.sdpa_causal_fixed_cache(q.transpose(1, 0, 2), np.repeat(k.transpose(1, 0, 2), 2, axis=0),
+                                      np.repeat(v.transpose(1, 0, 2), 2, axis=0), ctx)
+    np.testing.assert_allclose(got[0], dense[:, 0], rtol=2e-5, atol=2e-6)

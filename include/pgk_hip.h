@@ -38,6 +38,7 @@ typedef int pgk_status;
 #define PGK_ERR_HIP 2       /* HIP runtime failure (reference: CudaError) */
 #define PGK_ERR_UNSUPPORTED 3
 #define PGK_ERR_RCCL 4
+#define PGK_ERR_JIT 5        /* runtime compilation / module load / launch of a user kernel (reference: NvrtcError) */
 
 /* Same order as the reference's DataType enum (native/bindings/core_bindings.cpp:19-30). */
 typedef enum {
@@ -199,6 +200,30 @@ pgk_status pgk_argmax(const void* x, int rows, int n, pgk_dtype dt, int32_t* out
  * restated by oracle/cpu_ref.py sample_token_u.  Result: int32 per row in device memory. */
 pgk_status pgk_sample_token(const void* logits, int rows, int vocab, pgk_dtype dt, float temperature, int top_k,
                             float top_p, float u, const float* u_buf, int32_t* out_tokens, pgk_stream s);
+
+/* ----------------------------------------------------------------- runtime compilation ------ */
+/* native/jit/compiler.hpp + kernel.hpp (bound in native/bindings/jit_bindings.cpp:65-122): NVRTC -> PTX ->
+ * cuModuleLoadData -> cuLaunchKernel becomes hiprtc -> gfx950 code object -> hipModuleLoadData ->
+ * hipModuleLaunchKernel.  libhiprtc is dlopen'ed on first use (is_nvrtc_available's contract).  `rtc_code` outputs
+ * are hiprtcResult values (numerically nvrtcResult's) or 1000 NotLoaded / 1001 load failed / 1002 function not found /
+ * 1003 launch failed, as in src/pygpukit/jit/compiler.py:20-43. */
+int pgk_jit_available(void);
+const char* pgk_jit_library_path(void);
+pgk_status pgk_jit_version(int* major, int* minor);
+/* compile_to_ptx: NVRTC arch flags in `options` are dropped, --offload-arch=gfx950 is supplied; a program handle is
+ * returned even on a compilation error so that its log can be read. */
+pgk_status pgk_jit_compile(const char* source, const char* name, const char* const* options, int n_options,
+                           void** program_out, int* rtc_code);
+const char* pgk_jit_program_log(void* program);
+pgk_status pgk_jit_program_code(void* program, const void** code, size_t* size);
+void pgk_jit_program_destroy(void* program);
+/* JITKernel: module + function handle for one extern "C" __global__ function of a compiled program */
+pgk_status pgk_jit_kernel_create(void* program, const char* func_name, void** kernel_out, int* rtc_code);
+void pgk_jit_kernel_destroy(void* kernel);
+pgk_status pgk_jit_suggested_block_size(void* kernel, size_t dynamic_smem, int* block_size);
+/* args[i] points at the value of kernel argument i (cuLaunchKernel's kernelParams convention) */
+pgk_status pgk_jit_launch(void* kernel, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz,
+                          unsigned shared_bytes, void** args, pgk_stream s);
 
 /* ------------------------------------------------- paged KV cache / continuous batching ------ */
 /* ops.cuh:466-478 paged_attention_v1 (native/ops/attention/paged_attention.cuh:46-200): single-query attention over a

@@ -12,3 +12,5 @@ from pygpukit_amd import core, ops  # noqa: F401
 from pygpukit_amd.core import (CudaEvent, CudaGraph, DataType, GPUArray, Stream, bfloat16, device_synchronize, empty,  # noqa: F401
                               event_elapsed_ms, event_elapsed_us, float16, float32, float64, from_numpy, get_backend,
                               has_native_module, int4, int8, int16, int32, int64, ones, uint8, zeros)
+from pygpukit_amd.jit import (JITKernel, NvrtcError, NvrtcErrorCode, get_nvrtc_path, get_nvrtc_version, is_nvrtc_available,  # noqa: F401,E402
+                              jit, warmup)

@@ -85,6 +85,11 @@ _PROTOS = {
     "pgk_paged_cache_write": [_V, _V, _V, _V, _V, _I, _I, _I, _I, _I, _V],
     "pgk_scatter_last_token_logits": [_V, _V, _V, _V, _I, _I, _I, _V], "pgk_prepare_position_ids": [_V, _V, _V, _V, _V, _I, _V],
     "pgk_check_eos": [_V, _V, _I, _I, _V], "pgk_exclusive_cumsum_i32": [_V, _V, _I, _V],
+    "pgk_jit_version": [C.POINTER(_I), C.POINTER(_I)],
+    "pgk_jit_compile": [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), _I, c_void_pp, C.POINTER(_I)],
+    "pgk_jit_program_code": [_V, c_void_pp, C.POINTER(_Z)], "pgk_jit_kernel_create": [_V, C.c_char_p, c_void_pp, C.POINTER(_I)],
+    "pgk_jit_suggested_block_size": [_V, _Z, C.POINTER(_I)],
+    "pgk_jit_launch": [_V, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, c_void_pp, _V],
     "pgk_sample_token": [_V, _I, _I, _I, _F, _I, _F, _F, _V, _V, _V],
     "pgk_sdpa_causal": [_V, _V, _V, _V, _I, _I, _I, _I, _I, _F, _I64, _I64, _I64, _I64, _I64, _I64, _I, _V],
     "pgk_sdpa_fixed_cache": [_V, _V, _V, _V, _I, _I, _I, _I, _I, _F, _I, _V, _V, _I, _V],
@@ -103,7 +108,10 @@ _PROTOS = {
 }
 _NON_STATUS = {"pgk_last_error": ([], C.c_char_p), "pgk_version": ([], C.c_char_p),
                "pgk_sdpa_decode_workspace_bytes": ([_I, _I, _I], C.c_size_t),
-               "pgk_paged_attention_workspace_bytes": ([_I, _I, _I, _I], C.c_size_t)}
+               "pgk_paged_attention_workspace_bytes": ([_I, _I, _I, _I], C.c_size_t),
+               "pgk_jit_available": ([], C.c_int), "pgk_jit_library_path": ([], C.c_char_p),
+               "pgk_jit_program_log": ([_V], C.c_char_p), "pgk_jit_program_destroy": ([_V], None),
+               "pgk_jit_kernel_destroy": ([_V], None)}
 
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + list(_NON_STATUS))
 

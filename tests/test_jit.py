@@ -6,7 +6,9 @@ from __future__ import annotations
 import numpy as np
 import pytest
 
-from pygpukit_amd import jit as J
+import importlib
+
+J = importlib.import_module("pygpukit_amd.jit")   # `pygpukit_amd.jit` the attribute is the jit() function, as in the reference
 
 SCALE_SRC = '''
 extern "C" __global__ void scale(float* x, float factor, int n) {

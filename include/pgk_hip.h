@@ -201,6 +201,21 @@ pgk_status pgk_argmax(const void* x, int rows, int n, pgk_dtype dt, int32_t* out
 pgk_status pgk_sample_token(const void* logits, int rows, int vocab, pgk_dtype dt, float temperature, int top_k,
                             float top_p, float u, const float* u_buf, int32_t* out_tokens, pgk_stream s);
 
+/* ------------------------------------------------------------------ safetensors reader ------ */
+/* SafeTensorsFile (src/pygpukit/llm/safetensors.py:122-235 over rust/pygpukit-core/src/llm/tensor_loader.rs): the file
+ * is mmap'ed read-only and its JSON header parsed once.  dtype ids are safetensors.py:28-43 (0 F32, 1 F16, 2 BF16, 3 F64,
+ * 4 F8_E4M3, 5 F8_E5M2, 6 I32, 7 I64, 8 I16, 9 I8, 10 U8, 11 BOOL); `offset` is from the start of the file. */
+pgk_status pgk_st_open(const char* path, void** handle);
+void pgk_st_close(void* handle);
+int pgk_st_num_tensors(void* handle);
+uint64_t pgk_st_file_size(void* handle);
+const char* pgk_st_tensor_name(void* handle, int i);
+pgk_status pgk_st_tensor_info(void* handle, const char* name, int* dtype, int* ndim, int64_t* shape8, uint64_t* offset,
+                              uint64_t* nbytes);
+pgk_status pgk_st_tensor_data(void* handle, const char* name, const void** ptr, uint64_t* nbytes);
+/* mapped file -> device without a host copy (loader.py:160-175 memcpy_ptr_to_device) */
+pgk_status pgk_st_upload(void* handle, const char* name, void* dst_device, uint64_t dst_bytes, pgk_stream s);
+
 /* ----------------------------------------------------------------- runtime compilation ------ */
 /* native/jit/compiler.hpp + kernel.hpp (bound in native/bindings/jit_bindings.cpp:65-122): NVRTC -> PTX ->
  * cuModuleLoadData -> cuLaunchKernel becomes hiprtc -> gfx950 code object -> hipModuleLoadData ->

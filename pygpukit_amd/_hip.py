@@ -85,6 +85,9 @@ _PROTOS = {
     "pgk_paged_cache_write": [_V, _V, _V, _V, _V, _I, _I, _I, _I, _I, _V],
     "pgk_scatter_last_token_logits": [_V, _V, _V, _V, _I, _I, _I, _V], "pgk_prepare_position_ids": [_V, _V, _V, _V, _V, _I, _V],
     "pgk_check_eos": [_V, _V, _I, _I, _V], "pgk_exclusive_cumsum_i32": [_V, _V, _I, _V],
+    "pgk_st_open": [C.c_char_p, c_void_pp],
+    "pgk_st_tensor_info": [_V, C.c_char_p, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+    "pgk_st_tensor_data": [_V, C.c_char_p, c_void_pp, C.POINTER(C.c_uint64)], "pgk_st_upload": [_V, C.c_char_p, _V, C.c_uint64, _V],
     "pgk_jit_version": [C.POINTER(_I), C.POINTER(_I)],
     "pgk_jit_compile": [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), _I, c_void_pp, C.POINTER(_I)],
     "pgk_jit_program_code": [_V, c_void_pp, C.POINTER(_Z)], "pgk_jit_kernel_create": [_V, C.c_char_p, c_void_pp, C.POINTER(_I)],
@@ -109,6 +112,8 @@ _PROTOS = {
 _NON_STATUS = {"pgk_last_error": ([], C.c_char_p), "pgk_version": ([], C.c_char_p),
                "pgk_sdpa_decode_workspace_bytes": ([_I, _I, _I], C.c_size_t),
                "pgk_paged_attention_workspace_bytes": ([_I, _I, _I, _I], C.c_size_t),
+               "pgk_st_close": ([_V], None), "pgk_st_num_tensors": ([_V], C.c_int), "pgk_st_file_size": ([_V], C.c_uint64),
+               "pgk_st_tensor_name": ([_V, _I], C.c_char_p),
                "pgk_jit_available": ([], C.c_int), "pgk_jit_library_path": ([], C.c_char_p),
                "pgk_jit_program_log": ([_V], C.c_char_p), "pgk_jit_program_destroy": ([_V], None),
                "pgk_jit_kernel_destroy": ([_V], None)}

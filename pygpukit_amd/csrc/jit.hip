@@ -155,12 +155,14 @@ pgk_status pgk_jit_kernel_create(void* program, const char* func_name, void** ke
     k->name = func_name;
     hipError_t e = hipModuleLoadData(&k->module, p->code.data());
     if (e != hipSuccess) {
+        (void)hipGetLastError();   // do not leave the failure in the runtime's sticky last-error slot
         delete k;
         *rtc_code = PGK_JIT_LOAD_FAILED;
         return set_error(PGK_ERR_JIT, "hipModuleLoadData failed: %s", hipGetErrorString(e));
     }
     e = hipModuleGetFunction(&k->fn, k->module, func_name);
     if (e != hipSuccess) {
+        (void)hipGetLastError();   // (a later kernel-launch check would otherwise report this lookup failure)
         (void)hipModuleUnload(k->module);
         delete k;
         *rtc_code = PGK_JIT_FUNCTION_NOT_FOUND;
@@ -193,6 +195,7 @@ pgk_status pgk_jit_launch(void* kernel, unsigned gx, unsigned gy, unsigned gz, u
     PGK_REQUIRE(kernel, "pgk_jit_launch: null kernel");
     PGK_REQUIRE(gx && gy && gz && bx && by && bz && (unsigned long long)bx * by * bz <= 1024, "pgk_jit_launch: bad launch shape");
     const hipError_t e = hipModuleLaunchKernel(((Kernel*)kernel)->fn, gx, gy, gz, bx, by, bz, shared_bytes, resolve_stream(s), args, nullptr);
+    if (e != hipSuccess) (void)hipGetLastError();
     if (e != hipSuccess) return set_error(PGK_ERR_JIT, "hipModuleLaunchKernel(%s) failed: %s", ((Kernel*)kernel)->name.c_str(), hipGetErrorString(e));
     return PGK_OK;
 }

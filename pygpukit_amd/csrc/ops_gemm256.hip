@@ -159,6 +159,114 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_bf16_kernel(const bf16* A,
     }
 }
 
+// ---- bf16, staggered phases: the two waves of a SIMD alternate between "read + DMA issue" and "32 MFMAs" ---------
+// In the kernel above both waves of a SIMD leave each barrier together, request fragments together and want the MFMA
+// pipe together: the pipe idles while both wait (57 % busy).  Here the stage is half a K tile ([256 rows][32 k] per
+// operand, 64-byte rows; four stages in the same 128 KiB, three in flight) and a wave's work on stage s is two phases,
+//     A(s): request the 12 fragments of stage s, issue the DMA of stage s+3, wait for the fragments  | barrier
+//     B(s): 32 MFMAs                                                                                  | barrier
+// with waves 4-7 (the second wave of every SIMD) running ONE PHASE BEHIND waves 0-3 (one extra barrier up front, one
+// at the end for the others): whenever one wave of a SIMD multiplies, the other one reads.  A stage is refilled one
+// phase after its last reader finished (lgkmcnt(0) before that phase's barrier); its arrival is ordered by a counted
+// vmcnt(8) - two younger stages may stay in flight - at the end of the phase before the first group reads it, which
+// is B(s) for waves 0-3 and A(s) for waves 4-7.  DMAs past the end of K re-read the last stage (never consumed) so the
+// count is constant.  64-byte rows: chunk c of row r at r*64 + ((c ^ ((r >> 2) & 3)) << 4) (conflict-free b128 reads).
+template <int EPI>
+__global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A, const bf16* W, const bf16* bias, void* Cv,
+                                                                    int M, int N, int K, int ntm, int ntn) {
+    extern __shared__ __attribute__((aligned(16))) char g2_smem[];   // 4 stages x (A 16 KiB | W 16 KiB)
+    constexpr int HALF = 256 * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 2, wc = wid & 3, q = lane >> 4, l15 = lane & 15;
+    const int late = __builtin_amdgcn_readfirstlane(wr);     // wave-uniform by construction: scalar branches around barriers
+    int tm, tn;
+    g2_tile_of(blockIdx.x, ntm * ntn, ntm, ntn, tm, tn);
+    const int m0 = tm * G2_BM, n0 = tn * G2_BN;
+
+    const int drow = wid * 32 + (lane >> 2);                 // one DMA instruction = 16 rows x 64 B
+    const int dchunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const bf16* a_src0 = A + (size_t)min(m0 + drow, M - 1) * K + dchunk * 8;
+    const bf16* a_src1 = A + (size_t)min(m0 + drow + 16, M - 1) * K + dchunk * 8;
+    const bf16* w_src0 = W + (size_t)min(n0 + drow, N - 1) * K + dchunk * 8;
+    const bf16* w_src1 = W + (size_t)min(n0 + drow + 16, N - 1) * K + dchunk * 8;
+    const uint32_t lds0 = g2_lds_addr(g2_smem);
+    const int nh = K / 32;
+    auto stage = [&](int h, int buf) {
+        const int k = min(h, nh - 1) * 32;
+        const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds0 + buf * 2 * HALF + wid * 2048);
+        g2_dma16(a_src0 + k, a_dst);
+        g2_dma16(a_src1 + k, a_dst + 1024);
+        g2_dma16(w_src0 + k, a_dst + HALF);
+        g2_dma16(w_src1 + k, a_dst + HALF + 1024);
+    };
+
+    f32x4_g acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_g{0.f, 0.f, 0.f, 0.f};
+    const int f_off = l15 * 64 + ((q ^ ((l15 >> 2) & 3)) << 4);
+    const int a_base = wr * 128 * 64, w_base = HALF + wc * 64 * 64;
+    uint4 fa[8], fb[4];
+
+    stage(0, 0);
+    stage(1, 1);
+    stage(2, 2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();                  // waves 4-7 start one phase behind
+#define G2S_STEP(S, BUF)                                                                                     \
+    {   /* phase A */                                                                                        \
+        const char* As = g2_smem + (BUF) * 2 * HALF + a_base + f_off;                                        \
+        const char* Ws = g2_smem + (BUF) * 2 * HALF + w_base + f_off;                                        \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const uint4*>(As + i * 1024); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(Ws + j * 1024); \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        stage((S) + 3, ((BUF) + 3) & 3);                                                                     \
+        if (late) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                \
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        /* phase B */                                                                                        \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                        \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_g, fa[i]),     \
+                                                                    __builtin_bit_cast(bf16x8_g, fb[j]), acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (!late) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                          \
+        __builtin_amdgcn_s_barrier();                                                                        \
+    }
+    int s = 0;
+    for (; s + 4 <= nh; s += 4) {
+        G2S_STEP(s, 0) G2S_STEP(s + 1, 1) G2S_STEP(s + 2, 2) G2S_STEP(s + 3, 3)
+    }
+    if (s < nh) {   // K % 64 == 0: an even number of stages, so two remain at most
+        G2S_STEP(s, 0) G2S_STEP(s + 1, 1)
+    }
+#undef G2S_STEP
+    if (!late) __builtin_amdgcn_s_barrier();                 // match the extra barrier of waves 4-7
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // retire the phantom DMAs before the LDS is given back
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wc * 64 + j * 16 + l15;
+        if (col >= N) continue;
+        float b = 0.f;
+        if constexpr (EPI == 0) b = bias ? to_f(bias[col]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wr * 128 + i * 16 + q * 4 + r;
+                if (row >= M) continue;
+                if constexpr (EPI == 0) reinterpret_cast<bf16*>(Cv)[(size_t)row * N + col] = from_f<bf16>(acc[i][j][r] + b);
+                else reinterpret_cast<float*>(Cv)[(size_t)row * N + col] += acc[i][j][r];
+            }
+    }
+}
+
 // ---- fp8 x fp8 with 128-wide block scales on the same structure --------------------------------------------
 // K tile = 128 fp8 = one scale block: per tile the 256 row scales of A (fp32) and the two weight-block scales of
 // the tile's 256 columns (bf16) are DMA'd into a small LDS array next to the operand tiles - every global load
@@ -308,6 +416,19 @@ pgk_status gemm256_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void*
         attr_done = true;
     }
     const int ntm = ceil_div(M, G2_BM), ntn = ceil_div(N, G2_BN);
+    const char* e = getenv("PGK_GEMM256S");          // 0: two full stages, waves in lockstep; default: staggered phases
+    if (!e || atoi(e) != 0) {
+        static bool attr_s = false;
+        if (!attr_s) {
+            PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_bf16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+            PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+            attr_s = true;
+        }
+        if (accum_f32) gemm256s_bf16_kernel<1><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn);
+        else gemm256s_bf16_kernel<0><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn);
+        PGK_CHECK_HIP(hipGetLastError());
+        return PGK_OK;
+    }
     if (accum_f32) gemm256_bf16_kernel<1><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn);
     else gemm256_bf16_kernel<0><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn);
     PGK_CHECK_HIP(hipGetLastError());

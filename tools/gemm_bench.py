@@ -20,6 +20,18 @@ def main():
     dims = [int(x) for x in sys.argv[2:]]
     _hip.require_device()
     rng = np.random.default_rng(0)
+    import os
+    fill = os.environ.get("FILL", "normal")     # operand statistics change the clock the chip holds (DVFS): normal | uniform | zeros
+    gen = rng
+
+    class _R:   # same call sites, different operand statistics
+        def standard_normal(self, shape):
+            return gen.uniform(-1.0, 1.0, shape) if fill == "uniform" else (np.zeros(shape) if fill == "zeros" else gen.standard_normal(shape))
+
+        def integers(self, *a, **k):
+            return gen.integers(*a, **k)
+
+    rng = _R()
     for i in range(0, len(dims), 3):
         M, N, K = dims[i:i + 3]
         a16 = (rng.standard_normal((M, K)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)

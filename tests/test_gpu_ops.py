@@ -379,6 +379,23 @@ def test_gemm256_bf16_matches_oracle_and_128_tile_kernel(shape, monkeypatch):
     assert rel_err(c256, c128) < 3e-3
 
 
+def test_w8a16_gemm_large_goes_through_dequant_and_gemm256(monkeypatch):
+    """Large w8a16 products dequantise the weight once and use the LDS-DMA bf16 kernel; result equals the 128-tile
+    in-staging-dequant kernel on the same inputs up to accumulation order."""
+    rng = np.random.default_rng(34)
+    M, N, K = 512, 768, 512
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    codes, sbits = O.quantize_fp8_e4m3_block(w)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    ref = O.bf16_round(a) @ O.dequantize_fp8_e4m3_block(codes, sbits).T
+    args = [dev(a, "bfloat16"), from_numpy(codes), from_numpy(sbits)]
+    monkeypatch.setenv("PGK_GEMM256", "1")
+    c256 = host(ops.w8a16_gemm_nk(*args))
+    monkeypatch.setenv("PGK_GEMM256", "0")
+    c128 = host(ops.w8a16_gemm_nk(*args))
+    assert rel_err(c256, ref) < 1e-2 and rel_err(c128, ref) < 1e-2 and rel_err(c256, c128) < 3e-3
+
+
 def test_gemm256_exact_integers(monkeypatch):
     """Small integers are exact in bf16 and fp32: the two kernels and the oracle must agree bit for bit."""
     rng = np.random.default_rng(32)

@@ -357,14 +357,18 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
                 fa[i] = i32x8_g{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
                 sc[i] = *reinterpret_cast<const f32x4_g*>(Ss + (wr * 128 + (half * 4 + i) * 16 + q * 4) * 4) * swv;
             }
+            // software-pipelined by one: the scale-and-add of product n runs under MFMA n+1 (written the obvious way,
+            // every MFMA is followed by the FMAs that wait for its own result: MFMA latency exposed 16 times)
             __builtin_amdgcn_s_setprio(1);
+            f32x4_g tp = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[0], fb[0], f32x4_g{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4_g t = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], f32x4_g{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
-                    acc[half * 4 + i][j] += t * sc[i];
-                }
+            for (int n = 1; n < 16; ++n) {
+                const f32x4_g tc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[n >> 2], fb[n & 3], f32x4_g{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
+                acc[half * 4 + ((n - 1) >> 2)][(n - 1) & 3] += tp * sc[(n - 1) >> 2];
+                __builtin_amdgcn_sched_barrier(0);
+                tp = tc;
+            }
+            acc[half * 4 + 3][3] += tp * sc[3];
             __builtin_amdgcn_s_setprio(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -852,7 +852,9 @@ struct Engine {
     pgk_model_config_t cfg;
     const bf16 *embed, *lm_head, *final_norm;
     std::vector<pgk_layer_weights_t> layers;
-    int nsplit = 1, lm_blocks = 1, log_cap = 4096;
+    int nsplit = 1, lm_blocks = 1, lm_cap = 1, log_cap = 4096;
+    bool batched_mfma = true;   // chunks of 9..16 sequences use engine_batched.cuh (PGK_BATCHED_MFMA=0: GEMV kernels, =2: from 3 up)
+    int batched_min = 9;
     int skip_attn = 0;         // PGK_DEBUG_SKIP & 16: do not launch attention at all (timing ablation)
     bool fused_attn = false;   // attn + o_proj in one kernel (short contexts, bf16 W_o)
     int oproj_rows = 32;       // W_o rows per workgroup on the fused path
@@ -888,6 +890,10 @@ static pgk_status dev_alloc(Engine* e, void** p, size_t bytes, size_t* acct) {
     if (acct) *acct += bytes;
     return PGK_OK;
 }
+
+typedef __bf16 bf16x8_b __attribute__((ext_vector_type(8)));
+typedef float f32x4_b __attribute__((ext_vector_type(4)));
+#include "engine_batched.cuh"
 
 template <class WT, class XT, int M, int R, int PRO, int EPI, int C>
 static pgk_status launch_fused_c(const FusedArgs& a, int n_out, hipStream_t st, int force_grid) {
@@ -1056,13 +1062,74 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
     return PGK_OK;
 }
 
+// 3..16 sequences per chunk: every projection on the MFMA kernels of engine_batched.cuh (cost independent of M),
+// attention on the split-KV path.  Same launch sequence as decode_chunk's unfused branch: 6 L + 2.
+template <class WT>
+static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipStream_t st, int* launches) {
+    const auto& c = e->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size, D = c.head_dim, QD = c.num_heads * D, NQKV = e->qkv_dim();
+    float* h = e->h + (size_t)b0 * H;
+    mark(-1, st);
+    for (int l = 0; l < c.num_layers; ++l) {
+        const auto& L = e->layers[l];
+        FusedArgs a{};
+        a.w = L.w_qkv; a.wscale = (const bf16*)L.s_qkv; a.N = NQKV; a.K = H;
+        a.h = h; a.gamma = (const bf16*)L.attn_norm; a.eps = c.norm_eps;
+        a.out = e->qkv + (size_t)b0 * NQKV; a.ld_out = NQKV;
+        if (pgk_status r = launch_batched<WT, PRO_NORM, EPI_STORE>(a, M, st)) return r;
+        mark(KC_NORM_QKV, st);
+        if (!e->skip_attn) {
+            if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, false, st)) return r; }
+            else { if (pgk_status r = launch_attn<64>(e, l, b0, M, false, st)) return r; }
+        }
+        mark(KC_ATTN, st);
+        a = FusedArgs{};
+        a.w = L.w_o; a.wscale = (const bf16*)L.s_o; a.N = H; a.K = QD;
+        a.xin = e->attnv + (size_t)b0 * QD;
+        a.res = h; a.out = h; a.ld_out = H;
+        if (pgk_status r = launch_batched<WT, PRO_PLAIN, EPI_RESID>(a, M, st)) return r;
+        mark(KC_OPROJ, st);
+        a = FusedArgs{};
+        a.w = L.w_gate_up; a.wscale = (const bf16*)L.s_gate_up; a.N = I; a.K = H;
+        a.h = h; a.gamma = (const bf16*)L.mlp_norm; a.eps = c.norm_eps;
+        a.out = e->act + (size_t)b0 * I; a.ld_out = I;
+        if (pgk_status r = launch_batched<WT, PRO_NORM, EPI_SWIGLU>(a, M, st)) return r;
+        mark(KC_GATEUP, st);
+        a = FusedArgs{};
+        a.w = L.w_down; a.wscale = (const bf16*)L.s_down; a.N = H; a.K = I;
+        a.xin = e->act + (size_t)b0 * I;
+        a.res = h; a.out = h; a.ld_out = H;
+        if (pgk_status r = launch_batched<WT, PRO_PLAIN, EPI_RESID>(a, M, st)) return r;
+        mark(KC_DOWN, st);
+        *launches += 6;
+    }
+    const int nblk = ceil_div(c.vocab_size, 16) < 2048 ? ceil_div(c.vocab_size, 16) : 2048;
+    FusedArgs a{};
+    a.w = e->lm_head; a.N = c.vocab_size; a.K = H;
+    a.h = h; a.gamma = e->final_norm; a.eps = c.norm_eps;
+    a.out = e->logits + (size_t)b0 * c.vocab_size; a.ld_out = c.vocab_size;
+    a.amax_val = e->amax_val + (size_t)b0 * e->lm_cap; a.amax_idx = e->amax_idx + (size_t)b0 * e->lm_cap;
+    if (pgk_status r = launch_batched<bf16, PRO_NORM, EPI_LOGITS>(a, M, st, nblk)) return r;
+    mark(KC_LMHEAD, st);
+    finalize_kernel<<<M, 256, 0, st>>>(a.amax_val, a.amax_idx, nblk, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
+                                       e->cfg.max_batch, e->log_cap, e->embed, h, H, last ? 1 : 0, b0 == 0 ? e->clk_log : nullptr,
+                                       e->rope_cos, e->rope_sin, e->cur_cos + (size_t)b0 * (D / 2), e->cur_sin + (size_t)b0 * (D / 2),
+                                       D / 2, c.max_seq_len);
+    PGK_CHECK_HIP(hipGetLastError());
+    mark(KC_ARGMAX, st);
+    *launches += 2;
+    return PGK_OK;
+}
+
 template <class WT>
 static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* launches) {
     int b0 = 0;
     while (b0 < batch) {
         const int rem = batch - b0;
         pgk_status r;
-        if (rem >= 8) { r = decode_chunk<WT, bf16, 8>(e, b0, rem == 8, st, launches); b0 += 8; }
+        // the MFMA projections cost the same for 9 as for 16 sequences; up to 8 the GEMV kernels are faster (measured)
+        if (rem >= e->batched_min && e->batched_mfma) { const int m = rem > 16 ? 16 : rem; r = decode_chunk_batched<WT>(e, b0, m, rem == m, st, launches); b0 += m; }
+        else if (rem >= 8) { r = decode_chunk<WT, bf16, 8>(e, b0, rem == 8, st, launches); b0 += 8; }
         else if (rem >= 4) { r = decode_chunk<WT, bf16, 4>(e, b0, rem == 4, st, launches); b0 += 4; }
         else if (rem >= 2) { r = decode_chunk<WT, float, 2>(e, b0, rem == 2, st, launches); b0 += 2; }
         else { r = decode_chunk<WT, float, 1>(e, b0, true, st, launches); b0 += 1; }
@@ -1138,8 +1205,15 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
     A((void**)&e->attnv, (size_t)B * c.num_heads * D * 4, &e->ws_bytes);
     A((void**)&e->act, (size_t)B * c.intermediate_size * 4, &e->ws_bytes);
     A((void**)&e->logits, (size_t)B * c.vocab_size * 4, &e->ws_bytes);
-    A((void**)&e->amax_val, (size_t)B * e->lm_blocks * 4, &e->ws_bytes);
-    A((void**)&e->amax_idx, (size_t)B * e->lm_blocks * 4, &e->ws_bytes);
+    e->lm_cap = e->lm_blocks > ceil_div(c.vocab_size, 16) ? e->lm_blocks : ceil_div(c.vocab_size, 16);   // per-sequence argmax partial slots
+    {
+        const char* ev = getenv("PGK_BATCHED_MFMA");
+        e->batched_min = (ev && atoi(ev) == 2) ? 3 : 9;
+        e->batched_mfma = !(ev && atoi(ev) == 0) && c.hidden_size % 128 == 0 && c.intermediate_size % 128 == 0 &&
+                          (c.num_heads * c.head_dim) % 128 == 0;
+    }
+    A((void**)&e->amax_val, (size_t)B * e->lm_cap * 4, &e->ws_bytes);
+    A((void**)&e->amax_idx, (size_t)B * e->lm_cap * 4, &e->ws_bytes);
     A((void**)&e->clk_log, (size_t)e->log_cap * 16, &e->ws_bytes);
     if (r != PGK_OK) { pgk_engine_destroy(e); return r; }
     // RoPE tables in fp32, same formula as the reference (src/pygpukit/llm/layers/rope.py:13-24):

@@ -1,0 +1,245 @@
+// Batched decode projections on MFMA (3 <= M <= 16 sequences per launch), included by engine.hip.
+//
+// The GEMV kernels of engine.hip score every weight chunk against M activation rows with VALU dot products: 32 packed
+// dot instructions per 16-byte weight chunk at M = 8, and the kernel turns instruction-bound (gate_up 9.3 us, lm_head
+// 86 us at M = 8 against 5.7 / 50 us at M = 1).  Here the M rows are the (zero-padded) A operand of
+// v_mfma_f32_16x16x32_bf16 and 16 weight rows are its B operand, loaded straight from HBM in fragment shape
+// (lane l: W[n0 + (l&15)][k + 8*(l>>4) ..+8], the layout of ops_wsgemm.hip): one MFMA replaces those 32 instructions and
+// the cost of a projection no longer depends on M.
+//   workgroup = 4 waves = 16 output rows (SWIGLU: 16 gate rows and their 16 up rows); the waves split K four ways
+//   (every lane's weight loads - K/128 of them - are issued before the prologue touches the activations), partial
+//   16x16 tiles are summed through LDS; prologue = RMSNorm (or plain copy) of the M rows into an LDS image laid out
+//   [k/8][MP] x 16 B so that an A-fragment read is 64 consecutive 16-byte slots; epilogues as in engine.hip
+//   (store / residual add / SiLU(g)*u / logits + per-workgroup argmax partials, lowest index on ties).
+// fp8 weights: 8 codes per lane per step, widened to bf16 with the block scale in registers (as ops_wsgemm.hip).
+
+// MP: activation rows held in LDS (8 or 16).  S: 32-k steps per wave preloaded into registers (K = 128 S when it is one of
+// the instantiated 8 / 16 / 24; any further steps stream through a plain loop).
+template <class WT, int PRO, int EPI, int MP, int S>
+__global__ __launch_bounds__(256) void batched_mfma_kernel(FusedArgs a, int M, int steps /* K / 128 per wave */, int nblk_logits) {
+    constexpr bool FP8 = std::is_same<WT, fp8e4m3>::value;
+    constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;       // weight row groups per workgroup
+    constexpr int MAXS = S > 0 ? S : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // x image [K/8][MP] x 16 B | partial tiles
+    __shared__ float s_ss[4][16];
+    const int K = a.K, N = a.N;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, q = lane >> 4, l15 = lane & 15;
+    const int ngroups = (N + 15) >> 4;                     // 16-row groups; a workgroup takes groups blockIdx.x, + gridDim.x, ...
+    const int kw0 = wid * steps * 32;                      // first k of this wave
+    uint4 wv[NT][MAXS];
+    float wsc[NT][MAXS];
+    auto load_w = [&](int n0) {
+        const int nrow = min(n0 + l15, N - 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const size_t row = (size_t)(t == 0 ? nrow : N + nrow);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int k = kw0 + s * 32 + 8 * q;
+                if constexpr (FP8) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(a.w) + row * K + k);
+                    wv[t][s] = make_uint4(v.x, v.y, 0, 0);
+                    wsc[t][s] = to_f(a.wscale[(row >> 7) * (size_t)(K >> 7) + (k >> 7)]);
+                } else {
+                    wv[t][s] = load_nt16(reinterpret_cast<const bf16*>(a.w) + row * K + k);
+                }
+            }
+        }
+    };
+    // ---- weight loads of the first group's K quarter, all issued before the prologue touches the activations ----
+    load_w(blockIdx.x * 16);
+    const int em = tid >> 4, en = tid & 15;                // epilogue element of this thread: (row em, column n0 + en)
+
+    // ---- prologue: M rows -> bf16 LDS image, chunk c (8 k) of row m at (c * MP + m) * 16 ----
+    // Rows are unrolled to MP with clamped addresses and masked use (a runtime row loop would index registers
+    // dynamically and wait per load); chunk loops have a uniform trip count for the same reason.
+    const int nchunk = K >> 3;
+    const float* src = (PRO == PRO_NORM) ? a.h : a.xin;
+    if constexpr (PRO == PRO_NORM) {
+        float ss[MP];
+#pragma unroll
+        for (int m = 0; m < MP; ++m) ss[m] = 0.f;
+        for (int c0 = 0; c0 < nchunk; c0 += 256) {
+            const int c = min(c0 + tid, nchunk - 1);
+            const bool live = c0 + tid < nchunk;
+            float4 v0[MP], v1[MP];
+#pragma unroll
+            for (int m = 0; m < MP; ++m) {
+                v0[m] = *reinterpret_cast<const float4*>(src + (size_t)min(m, M - 1) * K + c * 8);
+                v1[m] = *reinterpret_cast<const float4*>(src + (size_t)min(m, M - 1) * K + c * 8 + 4);
+            }
+#pragma unroll
+            for (int m = 0; m < MP; ++m) {
+                const float p = v0[m].x * v0[m].x + v0[m].y * v0[m].y + v0[m].z * v0[m].z + v0[m].w * v0[m].w + v1[m].x * v1[m].x +
+                                v1[m].y * v1[m].y + v1[m].z * v1[m].z + v1[m].w * v1[m].w;
+                ss[m] += live ? p : 0.f;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MP; ++m) {
+            const float t = wave_sum(ss[m]);
+            if (lane == 0) s_ss[wid][m] = t;
+        }
+        __syncthreads();
+    }
+    for (int c0 = 0; c0 < nchunk; c0 += 256) {
+        const int c = min(c0 + tid, nchunk - 1);
+        float g[8];
+        if constexpr (PRO == PRO_NORM) {
+            Vec<bf16> gr;
+            gr.load(a.gamma + c * 8);
+            gr.to_float(g);
+        }
+        float4 v0[MP], v1[MP];
+#pragma unroll
+        for (int m = 0; m < MP; ++m) {
+            v0[m] = *reinterpret_cast<const float4*>(src + (size_t)min(m, M - 1) * K + c * 8);
+            v1[m] = *reinterpret_cast<const float4*>(src + (size_t)min(m, M - 1) * K + c * 8 + 4);
+        }
+#pragma unroll
+        for (int m = 0; m < MP; ++m) {
+            float f[8] = {v0[m].x, v0[m].y, v0[m].z, v0[m].w, v1[m].x, v1[m].y, v1[m].z, v1[m].w};
+            if constexpr (PRO == PRO_NORM) {
+                const float inv = 1.0f / sqrtf((s_ss[0][m] + s_ss[1][m] + s_ss[2][m] + s_ss[3][m]) / K + a.eps);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = f[j] * inv * g[j];
+            }
+            Vec<bf16> o;
+            o.from_float(f);
+            if (m >= M) o.raw = make_uint4(0, 0, 0, 0);     // unused rows of the image are zero
+            *reinterpret_cast<uint4*>(smem + ((size_t)c * MP + m) * 16) = o.raw;   // (duplicate writes of the clamped tail chunk are identical)
+        }
+    }
+    __syncthreads();
+
+    // ---- body: one 16-row group per trip; the LDS image of the activations stays, the partial tiles have their own area ----
+    float* red = reinterpret_cast<float*>(smem + (size_t)nchunk * MP * 16);   // [NT][4 waves][16 m][16 n]
+    const int am = l15 & (MP - 1);
+    auto bfrag = [&](int t, int s) -> uint4 {
+        if constexpr (FP8) {
+            const f32x2 c0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)wv[t][s].x, false), c1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)wv[t][s].x, true);
+            const f32x2 c2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)wv[t][s].y, false), c3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)wv[t][s].y, true);
+            const float sc = wsc[t][s];
+            return make_uint4(pack_bf16x2(c0.x * sc, c0.y * sc), pack_bf16x2(c1.x * sc, c1.y * sc), pack_bf16x2(c2.x * sc, c2.y * sc),
+                              pack_bf16x2(c3.x * sc, c3.y * sc));
+        } else {
+            return wv[t][s];
+        }
+    };
+    float bv = -INFINITY;          // EPI_LOGITS: best of this thread's elements over the workgroup's groups
+    int bi = 0x7FFFFFFF;
+    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int n0 = g * 16;
+        if (g != (int)blockIdx.x) load_w(n0);
+        float resv = 0.f;
+        if constexpr (EPI == EPI_RESID) resv = a.res[(size_t)min(em, M - 1) * a.ld_out + min(n0 + en, N - 1)];
+        f32x4_b acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4_b{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int kc = (kw0 >> 3) + s * 4 + q;
+            const uint4 af = *reinterpret_cast<const uint4*>(smem + ((size_t)kc * MP + am) * 16);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b, af), __builtin_bit_cast(bf16x8_b, bfrag(t, s)), acc[t], 0, 0, 0);
+        }
+        for (int s = S; s < steps; ++s) {          // steps beyond the preloaded ones stream through a plain loop
+            const int k = kw0 + s * 32 + 8 * q;
+            const uint4 af = *reinterpret_cast<const uint4*>(smem + ((size_t)((k >> 3)) * MP + am) * 16);
+            const int nrow = min(n0 + l15, N - 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const size_t row = (size_t)(t == 0 ? nrow : N + nrow);
+                uint4 b;
+                if constexpr (FP8) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(a.w) + row * K + k);
+                    const float sc = to_f(a.wscale[(row >> 7) * (size_t)(K >> 7) + (k >> 7)]);
+                    const f32x2 c0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, false), c1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, true);
+                    const f32x2 c2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, false), c3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, true);
+                    b = make_uint4(pack_bf16x2(c0.x * sc, c0.y * sc), pack_bf16x2(c1.x * sc, c1.y * sc), pack_bf16x2(c2.x * sc, c2.y * sc),
+                                   pack_bf16x2(c3.x * sc, c3.y * sc));
+                } else {
+                    b = load_nt16(reinterpret_cast<const bf16*>(a.w) + row * K + k);
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b, af), __builtin_bit_cast(bf16x8_b, b), acc[t], 0, 0, 0);
+            }
+        }
+        // sum the four K quarters: C tile element (m = 4 q + r, n = l15)
+        __syncthreads();                                    // the previous trip's partial tiles have been read
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((t * 4 + wid) * 16 + q * 4 + r) * 16 + l15] = acc[t][r];
+        __syncthreads();
+        float y[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float* p = red + (size_t)t * 4 * 256 + em * 16 + en;
+            y[t] = p[0] + p[256] + p[512] + p[768];
+        }
+        const bool ok = em < M && n0 + en < N;
+        const size_t o = (size_t)em * a.ld_out + n0 + en;
+        if constexpr (EPI == EPI_STORE) {
+            if (ok) a.out[o] = y[0];
+        } else if constexpr (EPI == EPI_RESID) {
+            if (ok) a.out[o] = resv + y[0];
+        } else if constexpr (EPI == EPI_SWIGLU) {
+            if (ok) a.out[o] = y[0] / (1.0f + __expf(-y[0])) * y[NT - 1];
+        } else {   // EPI_LOGITS
+            if (ok) {
+                a.out[o] = y[0];
+                if (y[0] > bv) { bv = y[0]; bi = n0 + en; }     // groups ascend: a later equal value never replaces an earlier one
+            }
+        }
+    }
+    if constexpr (EPI == EPI_LOGITS) {   // best of this workgroup's columns per row (lowest index on ties)
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (en == 0 && em < M) {
+            a.amax_val[(size_t)em * nblk_logits + blockIdx.x] = bv;
+            a.amax_idx[(size_t)em * nblk_logits + blockIdx.x] = bi;
+        }
+    }
+}
+
+template <class WT, int PRO, int EPI, int MP, int S>
+static pgk_status launch_batched_s(const FusedArgs& a, int M, int steps, int grid, size_t lds, hipStream_t st, int nblk_logits) {
+    static bool done = false;
+    if (lds > 48 * 1024 && !done) {
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&batched_mfma_kernel<WT, PRO, EPI, MP, S>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        done = true;
+    }
+    batched_mfma_kernel<WT, PRO, EPI, MP, S><<<grid, 256, lds, st>>>(a, M, steps, nblk_logits);
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
+}
+
+template <class WT, int PRO, int EPI>
+static pgk_status launch_batched(const FusedArgs& a, int M, hipStream_t st, int nblk_logits = 0) {
+    PGK_REQUIRE(a.K % 128 == 0 && M >= 1 && M <= 16, "batched decode projection: K=%d must be a multiple of 128 and M=%d in [1,16]", a.K, M);
+    const int steps = a.K / 128, ngroups = ceil_div(a.N, 16);
+    // the prologue (RMSNorm of the M rows) is per workgroup: large N (lm_head) runs 2048 workgroups over several groups each
+    const int grid = (EPI == EPI_LOGITS) ? nblk_logits : ngroups;
+    constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
+    const int mp = M <= 8 ? 8 : 16;
+    const size_t lds = (size_t)(a.K / 8) * mp * 16 + (size_t)NT * 4 * 256 * 4;
+    PGK_REQUIRE(lds <= 158 * 1024, "batched decode projection: K=%d does not fit the LDS image", a.K);
+#define PGK_BS(MPV, SV) return launch_batched_s<WT, PRO, EPI, MPV, SV>(a, M, steps, grid, lds, st, nblk_logits);
+    if (mp == 8) {
+        if (steps == 8) PGK_BS(8, 8)
+        if (steps == 16) PGK_BS(8, 16)
+        if (steps == 24) PGK_BS(8, 24)
+        PGK_BS(8, 0)
+    }
+    if (steps == 8) PGK_BS(16, 8)
+    if (steps == 16) PGK_BS(16, 16)
+    if (steps == 24) PGK_BS(16, 24)
+    PGK_BS(16, 0)
+#undef PGK_BS
+}

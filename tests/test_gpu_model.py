@@ -144,6 +144,34 @@ def test_engine_batch_of_independent_sequences(tiny_weights):
         assert got == want[b], f"sequence {b}"
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "fp8"])
+@pytest.mark.parametrize("B", [3, 8, 11, 19])
+def test_engine_batched_mfma_path_matches_gemv_path(tiny_weights, B, fmt, monkeypatch):
+    """Chunks of 3..16 sequences run the MFMA projections (engine_batched.cuh: 8-row and 16-row LDS images, a 16+3
+    split at B = 19); with PGK_BATCHED_MFMA=0 the same batch runs the GEMV kernels (fp32 activations in chunks of
+    1-2 sequences, bf16 in chunks of 4 / 8).  The difference is bf16 rounding of the activations and summation order:
+    logits agree to 6e-3 (the bf16 bar is 1e-2) and - for rows with a safe top-1 margin - the tokens are identical."""
+    rng = np.random.default_rng(60 + B)
+    prompts = [[int(t) for t in rng.integers(0, TINY["vocab_size"], int(rng.integers(1, 24)))] for _ in range(B)]
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PGK_BATCHED_MFMA", "2" if mode == "1" else "0")     # 2: MFMA chunks from 3 sequences up
+        eng = S.build_engine_from_weights(TINY, tiny_weights, max_seq_len=64, max_batch=B, weight_format=fmt)
+        first = [int(np.argmax(eng.prefill(p, seq=b))) for b, p in enumerate(prompts)]
+        eng.set_state(first, [len(p) for p in prompts])
+        for _ in range(3):
+            eng.decode_step(B)
+        eng.synchronize()
+        outs[mode] = (eng.logits(B).to_numpy().copy(), eng.read_tokens(B, 3).copy())
+    lg1, tk1 = outs["1"]
+    lg0, tk0 = outs["0"]
+    assert rel_err(lg1, lg0) < 6e-3, rel_err(lg1, lg0)
+    safe = np.array([margin(r) / np.abs(r).max() > 0.02 for r in lg0])
+    assert safe.sum() >= B // 2
+    np.testing.assert_array_equal(tk1[-1][safe], tk0[-1][safe])
+    np.testing.assert_array_equal(np.argmax(lg1, axis=1)[safe], np.argmax(lg0, axis=1)[safe])
+
+
 def test_decode_strategies_api(tiny_weights):
     model = S.build_model_from_weights(TINY, tiny_weights, dtype="bfloat16", max_pos=128)
     model.init_fixed_cache(128, "bfloat16")

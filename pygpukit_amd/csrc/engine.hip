@@ -429,6 +429,7 @@ struct AttnArgs {
     // split path
     float* part;          // [B][Hq][nsplit][D+2]
     int nsplit;
+    float* attn_direct;   // whole-context variant (nsplit == 1): normalised output [B][Hq][D], no merge launch
     // fused o_proj path
     const bf16* w_o;      // [H][Hq*D]
     int H, rows_per_block;
@@ -525,10 +526,11 @@ __device__ __forceinline__ void fold_new_token(const NewToken<D, G>& t, DecodeSt
 }
 
 // split path: grid (nsplit, Hkv, batch)
-template <int D, int G>
+template <int D, int G, bool DIRECT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     constexpr int LPR = D / 8, PPW = 64 / LPR, RS = D + 2;
     __shared__ float lds[4 * PPW * G * RS];
+    __shared__ float attn_out[DIRECT ? G * D : 1];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane % LPR;
     const int kvh = blockIdx.y, b = blockIdx.z;
     const int pos = a.positions[b];
@@ -547,8 +549,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     st.init();
     decode_walk<bf16, D, G>(a.kcache + head_off, a.vcache + head_off, c0, owns_new ? min(c1, pos) : c1, t.qf, lane, wid, st);
     if (owns_new && wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
-    decode_block_merge<D, G>(st, lds, a.part + (((size_t)b * a.hq + (size_t)kvh * G) * a.nsplit + blockIdx.x) * RS,
-                             (size_t)a.nsplit * RS, lane, wid);
+    if constexpr (DIRECT) {
+        // this workgroup saw the whole context: normalise here and skip the merge launch
+        decode_block_merge_lds<D, G>(st, lds, attn_out, lane, wid);
+        for (int e = threadIdx.x; e < G * D; e += 256) a.attn_direct[((size_t)b * a.hq + (size_t)kvh * G) * D + e] = attn_out[e];
+    } else {
+        decode_block_merge<D, G>(st, lds, a.part + (((size_t)b * a.hq + (size_t)kvh * G) * a.nsplit + blockIdx.x) * RS,
+                                 (size_t)a.nsplit * RS, lane, wid);
+    }
 }
 
 // split path, step 2: merge the nsplit (<= 64) chunk records of every head into the normalised attention
@@ -855,6 +863,7 @@ struct Engine {
     int nsplit = 1, lm_blocks = 1, lm_cap = 1, log_cap = 4096;
     bool batched_mfma = true;   // chunks of 9..16 sequences use engine_batched.cuh (PGK_BATCHED_MFMA=0: GEMV kernels, =2: from 3 up)
     int batched_min = 9;
+    bool attn_direct_ok = false;   // max_seq <= 512: batch attention in one workgroup per (sequence, kv head)
     int skip_attn = 0;         // PGK_DEBUG_SKIP & 16: do not launch attention at all (timing ablation)
     bool fused_attn = false;   // attn + o_proj in one kernel (short contexts, bf16 W_o)
     int oproj_rows = 32;       // W_o rows per workgroup on the fused path
@@ -961,18 +970,23 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
     a.nsplit = e->nsplit;
     a.w_o = (const bf16*)L.w_o; a.H = c.hidden_size; a.rows_per_block = e->oproj_rows;
     a.opart = e->opart ? e->opart + (size_t)b0 * c.num_kv_heads * c.hidden_size : nullptr;
-    dim3 grid = fused ? dim3(c.hidden_size / e->oproj_rows, c.num_kv_heads, m) : dim3(e->nsplit, c.num_kv_heads, m);
+    // batches at short context: one workgroup per (sequence, kv head) walks the whole context and writes the
+    // normalised output itself - Hkv * m workgroups, and the merge launch disappears
+    const bool direct = !fused && e->attn_direct_ok && m >= 4;
+    if (direct) { a.nsplit = 1; a.attn_direct = e->attnv + (size_t)b0 * c.num_heads * D; }
+    dim3 grid = fused ? dim3(c.hidden_size / e->oproj_rows, c.num_kv_heads, m) : dim3(direct ? 1 : e->nsplit, c.num_kv_heads, m);
 #define PGK_ATTN(GG)                                                               \
     case GG:                                                                       \
         if (fused) attn_oproj_kernel<D, GG><<<grid, 256, 0, st>>>(a);              \
-        else attn_decode_kernel<D, GG><<<grid, 256, 0, st>>>(a);                   \
+        else if (direct) attn_decode_kernel<D, GG, true><<<grid, 256, 0, st>>>(a); \
+        else attn_decode_kernel<D, GG, false><<<grid, 256, 0, st>>>(a);            \
         break;
     switch (G) {
         PGK_ATTN(1) PGK_ATTN(2) PGK_ATTN(4)
         default: return set_error(PGK_ERR_UNSUPPORTED, "engine: GQA group %d not in {1,2,4}", G);
     }
 #undef PGK_ATTN
-    if (!fused) {
+    if (!fused && !direct) {
         attn_merge_kernel<D><<<dim3(c.num_heads, m), D, 0, st>>>(a.part, e->attnv + (size_t)b0 * c.num_heads * D, c.num_heads, e->nsplit);
     }
     PGK_CHECK_HIP(hipGetLastError());
@@ -1014,7 +1028,7 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
             a.res = h; a.out = h; a.ld_out = H;
             if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_PLAIN, EPI_RESID>(a, H, st)) return r;
             mark(KC_OPROJ, st);
-            *launches += 2;
+            *launches += (e->attn_direct_ok && M >= 4) ? 1 : 2;   // o_proj (+ the merge kernel unless attention normalised in place)
         }
         // 4. act = silu(Wg x) * (Wu x), x = rmsnorm(h [+ sum of o_proj partials])
         a = FusedArgs{};
@@ -1101,7 +1115,7 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
         a.res = h; a.out = h; a.ld_out = H;
         if (pgk_status r = launch_batched<WT, PRO_PLAIN, EPI_RESID>(a, M, st)) return r;
         mark(KC_DOWN, st);
-        *launches += 6;
+        *launches += (e->attn_direct_ok && M >= 4) ? 5 : 6;
     }
     const int nblk = ceil_div(c.vocab_size, 16) < 2048 ? ceil_div(c.vocab_size, 16) : 2048;
     FusedArgs a{};
@@ -1209,6 +1223,8 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
     {
         const char* ev = getenv("PGK_BATCHED_MFMA");
         e->batched_min = (ev && atoi(ev) == 2) ? 3 : 9;
+        const char* ed = getenv("PGK_ATTN_DIRECT");
+        e->attn_direct_ok = c.max_seq_len <= 512 && !(ed && atoi(ed) == 0);
         e->batched_mfma = !(ev && atoi(ev) == 0) && c.hidden_size % 128 == 0 && c.intermediate_size % 128 == 0 &&
                           (c.num_heads * c.head_dim) % 128 == 0;
     }

@@ -381,6 +381,13 @@ pgk_status pgk_engine_replay(pgk_engine e, int n_steps, pgk_stream s);
 pgk_status pgk_engine_logits_ptr(pgk_engine e, void** logits_f32);
 pgk_status pgk_engine_read_tokens(pgk_engine e, int32_t* h_out, int batch, int n_steps, pgk_stream s);
 pgk_status pgk_engine_reset_log(pgk_engine e, pgk_stream s);
+/* In-graph stochastic sampling (the graph-compatible sample_topk_to_buf_ptr of src/pygpukit/ops/sampling.py:40-71, for the
+ * whole-step graph): each step draws one token per sequence from the step's fp32 logits with pgk_sample_token's
+ * semantics; the uniform numbers are row (step counter % n_rows) of `h_uniforms` [n_rows][max_batch], copied to the device
+ * here.  temperature <= 0 restores greedy argmax.  Set before pgk_engine_capture; call again (same n_rows or fewer) to
+ * queue fresh uniforms between replays; temperature / top_k / top_p changes need a re-capture. */
+pgk_status pgk_engine_set_sampling(pgk_engine e, float temperature, int top_k, float top_p, const float* h_uniforms, int n_rows,
+                                   pgk_stream s);
 /* Diagnostic: per logged step, {s_memtime (shader clock ticks), s_memrealtime (100 MHz ticks)} stamped by the
  * step's last kernel: the in-kernel shader clock between two steps is d(memtime)/d(memrealtime) x 100 MHz
  * (MI355X_MICROARCH.md, DVFS give-back item 6).  h_out: uint64[2 * n_steps]. */

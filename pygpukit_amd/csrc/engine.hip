@@ -366,51 +366,67 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* amax_val, co
                                                        const bf16* embed, float* h, int H, int bump,
                                                        unsigned long long* clk_log, const float* rope_cos,
                                                        const float* rope_sin, float* cur_cos, float* cur_sin, int half,
-                                                       int max_seq) {
+                                                       int max_seq, int M, const int32_t* sampled) {
+    // ONE workgroup for the whole chunk (the step counter is read and bumped here: with a workgroup per sequence the
+    // bump of the last one could overtake another one's read).  Wave w owns sequences w, w+4, ...
+    __shared__ int s_tok[16], s_pos[16];
     __shared__ float sv[4];
     __shared__ int si[4];
-    __shared__ int s_tok, s_pos;
-    const int b = blockIdx.x;
-    float bv = -INFINITY;
-    int bi = 0x7FFFFFFF;
-    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
-        const float v = amax_val[(size_t)b * nblk + i];
-        const int ix = amax_idx[(size_t)b * nblk + i];
-        if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ov = __shfl_xor(bv, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 0) { sv[wid] = bv; si[wid] = bi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
-        if (bi == 0x7FFFFFFF) bi = 0;
-        s_tok = bi;
-        tokens[b] = bi;
-        const int npos = positions[b] + 1;
-        positions[b] = npos;
-        s_pos = min(npos, max_seq - 1);
-        const int step = step_counter[0];
-        if (step < log_cap) token_log[(size_t)step * log_width + b] = bi;
-        if (b == 0 && step < log_cap && clk_log) {  // shader-clock / 100 MHz wall-clock stamps (diagnostic only)
-            clk_log[2 * (size_t)step] = __builtin_amdgcn_s_memtime();
-            clk_log[2 * (size_t)step + 1] = __builtin_amdgcn_s_memrealtime();
+    const int step = step_counter[0];
+    // one sequence (the latency-critical case): all four waves scan its partials; otherwise a wave per sequence
+    const int span = (M == 1) ? 256 : 64, first = (M == 1) ? (int)threadIdx.x : lane;
+    for (int b = (M == 1) ? 0 : wid; b < M; b += 4) {
+        int bi;
+        if (sampled) {
+            bi = sampled[b];                                  // temperature / top-k / top-p draw (ops_sampling.hip)
+        } else {
+            float bv = -INFINITY;
+            bi = 0x7FFFFFFF;
+            for (int i = first; i < nblk; i += span) {
+                const float v = amax_val[(size_t)b * nblk + i];
+                const int ix = amax_idx[(size_t)b * nblk + i];
+                if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ov = __shfl_xor(bv, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (M == 1) {                                       // combine the four waves
+                if (lane == 0) { sv[wid] = bv; si[wid] = bi; }
+                __syncthreads();
+                bv = sv[0]; bi = si[0];
+#pragma unroll
+                for (int w = 1; w < 4; ++w)
+                    if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+            }
+            if (bi == 0x7FFFFFFF) bi = 0;
+        }
+        if (lane == 0 && (M > 1 || wid == 0)) {
+            s_tok[b] = bi;
+            tokens[b] = bi;
+            const int npos = positions[b] + 1;
+            positions[b] = npos;
+            s_pos[b] = min(npos, max_seq - 1);
+            if (step < log_cap) token_log[(size_t)step * log_width + b] = bi;
+            if (b == 0 && step < log_cap && clk_log) {  // shader-clock / 100 MHz wall-clock stamps (diagnostic only)
+                clk_log[2 * (size_t)step] = __builtin_amdgcn_s_memtime();
+                clk_log[2 * (size_t)step + 1] = __builtin_amdgcn_s_memrealtime();
+            }
         }
     }
     __syncthreads();
-    const bf16* row = embed + (size_t)s_tok * H;
-    for (int i = threadIdx.x; i < H; i += blockDim.x) h[(size_t)b * H + i] = to_f(row[i]);
-    for (int i = threadIdx.x; i < half; i += blockDim.x) {  // RoPE row of the next position
-        cur_cos[(size_t)b * half + i] = rope_cos[(size_t)s_pos * half + i];
-        cur_sin[(size_t)b * half + i] = rope_sin[(size_t)s_pos * half + i];
+    for (int b = 0; b < M; ++b) {
+        const bf16* row = embed + (size_t)s_tok[b] * H;
+        for (int i = threadIdx.x; i < H; i += 256) h[(size_t)b * H + i] = to_f(row[i]);
+        for (int i = threadIdx.x; i < half; i += 256) {  // RoPE row of the next position
+            cur_cos[(size_t)b * half + i] = rope_cos[(size_t)s_pos[b] * half + i];
+            cur_sin[(size_t)b * half + i] = rope_sin[(size_t)s_pos[b] * half + i];
+        }
     }
-    if (bump && b == (int)gridDim.x - 1 && threadIdx.x == 0) step_counter[0] += 1;
+    if (bump && threadIdx.x == 0) step_counter[0] = step + 1;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -863,7 +879,12 @@ struct Engine {
     int nsplit = 1, lm_blocks = 1, lm_cap = 1, log_cap = 4096;
     bool batched_mfma = true;   // chunks of 9..16 sequences use engine_batched.cuh (PGK_BATCHED_MFMA=0: GEMV kernels, =2: from 3 up)
     int batched_min = 9;
-    bool attn_direct_ok = false;   // max_seq <= 512: batch attention in one workgroup per (sequence, kv head)
+    bool attn_direct_ok = false;
+    // in-graph stochastic sampling (pgk_engine_set_sampling): temperature <= 0 keeps greedy argmax
+    float sample_temperature = 0.f, sample_top_p = 1.f;
+    int sample_top_k = 0, u_cap = 0;
+    float* u_ring = nullptr;       // [u_cap][max_batch] uniforms, row = step counter % u_cap
+    int32_t* sampled = nullptr;    // [max_batch]   // max_seq <= 512: batch attention in one workgroup per (sequence, kv head)
     int skip_attn = 0;         // PGK_DEBUG_SKIP & 16: do not launch attention at all (timing ablation)
     bool fused_attn = false;   // attn + o_proj in one kernel (short contexts, bf16 W_o)
     int oproj_rows = 32;       // W_o rows per workgroup on the fused path
@@ -994,6 +1015,16 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
 }
 
 // One decode step for sequences [b0, b0+M); `last` = this is the step's last chunk (bumps the step counter)
+pgk_status sample_rows_ring(const float* logits, int rows, int vocab, float temperature, int top_k, float top_p, const float* u_ring,
+                            int u_cap, int u_stride, const int32_t* step_counter, int32_t* out, hipStream_t st);
+
+// one draw per sequence of the chunk from the fp32 logits the lm_head kernel just wrote; the uniform numbers come from
+// the device ring row (step counter % u_cap), so a captured graph replays with fresh randomness the host queued up
+static pgk_status engine_sample(Engine* e, int b0, int M, hipStream_t st) {
+    return sample_rows_ring(e->logits + (size_t)b0 * e->cfg.vocab_size, M, e->cfg.vocab_size, e->sample_temperature, e->sample_top_k,
+                            e->sample_top_p, e->u_ring + b0, e->u_cap, e->cfg.max_batch, e->step_counter, e->sampled + b0, st);
+}
+
 template <class WT, class XT, int M>
 static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int* launches) {
     const auto& c = e->cfg;
@@ -1065,11 +1096,17 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
     a.amax_val = e->amax_val + (size_t)b0 * e->lm_blocks; a.amax_idx = e->amax_idx + (size_t)b0 * e->lm_blocks;
     if (pgk_status r = launch_fused<bf16, XT, M, 4, PRO_NORM, EPI_LOGITS>(a, c.vocab_size, st, e->lm_blocks)) return r;
     mark(KC_LMHEAD, st);
-    finalize_kernel<<<M, 256, 0, st>>>(e->amax_val + (size_t)b0 * e->lm_blocks, e->amax_idx + (size_t)b0 * e->lm_blocks,
+    const int32_t* sampled = nullptr;
+    if (e->sample_temperature > 0.f) {
+        if (pgk_status r = engine_sample(e, b0, M, st)) return r;
+        sampled = e->sampled + b0;
+        *launches += 1;
+    }
+    finalize_kernel<<<1, 256, 0, st>>>(e->amax_val + (size_t)b0 * e->lm_blocks, e->amax_idx + (size_t)b0 * e->lm_blocks,
                                        e->lm_blocks, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
                                        e->cfg.max_batch, e->log_cap, e->embed, h, H, last ? 1 : 0, b0 == 0 ? e->clk_log : nullptr,
                                        e->rope_cos, e->rope_sin, e->cur_cos + (size_t)b0 * (D / 2), e->cur_sin + (size_t)b0 * (D / 2),
-                                       D / 2, c.max_seq_len);
+                                       D / 2, c.max_seq_len, M, sampled);
     PGK_CHECK_HIP(hipGetLastError());
     mark(KC_ARGMAX, st);
     *launches += 2;
@@ -1125,10 +1162,16 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
     a.amax_val = e->amax_val + (size_t)b0 * e->lm_cap; a.amax_idx = e->amax_idx + (size_t)b0 * e->lm_cap;
     if (pgk_status r = launch_batched<bf16, PRO_NORM, EPI_LOGITS>(a, M, st, nblk)) return r;
     mark(KC_LMHEAD, st);
-    finalize_kernel<<<M, 256, 0, st>>>(a.amax_val, a.amax_idx, nblk, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
+    const int32_t* sampled = nullptr;
+    if (e->sample_temperature > 0.f) {
+        if (pgk_status r = engine_sample(e, b0, M, st)) return r;
+        sampled = e->sampled + b0;
+        *launches += 1;
+    }
+    finalize_kernel<<<1, 256, 0, st>>>(a.amax_val, a.amax_idx, nblk, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
                                        e->cfg.max_batch, e->log_cap, e->embed, h, H, last ? 1 : 0, b0 == 0 ? e->clk_log : nullptr,
                                        e->rope_cos, e->rope_sin, e->cur_cos + (size_t)b0 * (D / 2), e->cur_sin + (size_t)b0 * (D / 2),
-                                       D / 2, c.max_seq_len);
+                                       D / 2, c.max_seq_len, M, sampled);
     PGK_CHECK_HIP(hipGetLastError());
     mark(KC_ARGMAX, st);
     *launches += 2;
@@ -1269,6 +1312,8 @@ pgk_status pgk_engine_destroy(pgk_engine eh) {
     for (void* p : e->allocs) (void)pgk_free(p);
     if (e->pf) (void)pgk_free(e->pf);
     if (e->pf_tokens) (void)pgk_free(e->pf_tokens);
+    if (e->u_ring) (void)pgk_free(e->u_ring);
+    if (e->sampled) (void)pgk_free(e->sampled);
     delete e;
     return PGK_OK;
 }
@@ -1536,6 +1581,42 @@ pgk_status pgk_engine_read_clock(pgk_engine eh, uint64_t* h_out, int n_steps, pg
         PGK_CHECK_HIP(hipMemcpyAsync(h_out, e->clk_log, (size_t)n_steps * 16, hipMemcpyDeviceToHost, st));
         PGK_CHECK_HIP(hipStreamSynchronize(st));
     }
+    return PGK_OK;
+}
+
+// In-graph stochastic sampling.  temperature <= 0 restores greedy argmax.  `h_uniforms` [n_rows][max_batch] floats in
+// [0,1) are copied into the device ring (row r serves step counter r, modulo n_rows): queue as many rows as steps will be
+// replayed before the next call.  Must be set BEFORE pgk_engine_capture (it adds a node per chunk) and may be called
+// again afterwards with the same on/off state to refresh the uniforms or change temperature / top-k / top-p?  No:
+// those three are kernel arguments baked into the captured graph - re-capture after changing them.
+pgk_status pgk_engine_set_sampling(pgk_engine eh, float temperature, int top_k, float top_p, const float* h_uniforms, int n_rows,
+                                   pgk_stream s) {
+    PGK_REQUIRE(eh, "pgk_engine_set_sampling: null engine");
+    Engine* e = (Engine*)eh;
+    hipStream_t st = resolve_stream(s);
+    if (temperature <= 0.f) {
+        e->sample_temperature = 0.f;
+        return PGK_OK;
+    }
+    PGK_REQUIRE(top_k >= 0 && top_p > 0.f && top_p <= 1.f, "pgk_engine_set_sampling: need top_k >= 0 and 0 < top_p <= 1");
+    PGK_REQUIRE(h_uniforms && n_rows >= 1, "pgk_engine_set_sampling: uniforms missing");
+    const int B = e->cfg.max_batch;
+    if (n_rows > e->u_cap) {
+        PGK_CHECK_HIP(hipStreamSynchronize(st));
+        if (e->u_ring) pgk_free(e->u_ring);
+        e->u_ring = nullptr;
+        if (pgk_status r = pgk_malloc((void**)&e->u_ring, (size_t)n_rows * B * 4)) return r;
+        e->u_cap = n_rows;
+    }
+    if (!e->sampled) {
+        if (pgk_status r = pgk_malloc((void**)&e->sampled, (size_t)B * 4)) return r;
+    }
+    // a shorter refill keeps the ring size (the graph holds u_cap): rows beyond n_rows keep their previous values
+    PGK_CHECK_HIP(hipMemcpyAsync(e->u_ring, h_uniforms, (size_t)n_rows * B * 4, hipMemcpyHostToDevice, st));
+    PGK_CHECK_HIP(hipStreamSynchronize(st));
+    e->sample_temperature = temperature;
+    e->sample_top_k = top_k;
+    e->sample_top_p = top_p;
     return PGK_OK;
 }
 

@@ -61,7 +61,8 @@ __device__ __forceinline__ V smp_scan(V v, V* wave_tot /* [17] */, V* total) {
 
 template <class T>
 __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const T* logits_all, int V, float temperature, int top_k, float top_p,
-                                                            float u_val, const float* u_buf, int32_t* out) {
+                                                            float u_val, const float* u_buf, int32_t* out, const int32_t* step_counter = nullptr,
+                                                            int u_cap = 0, int u_stride = 0) {
     __shared__ unsigned long long hist[256];
     __shared__ unsigned long long tot64[17];
     __shared__ int tot32[17];
@@ -211,7 +212,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const T* logits_all
     for_each_final([&](int i, float z) { mine += smp_mass(z, mx); my_last = i; });
     unsigned long long total;
     const unsigned long long base = smp_scan<unsigned long long>(mine, tot64, &total);
-    const float u = u_buf ? *u_buf : u_val;
+    // u: a host value, one device float shared by the rows, or (engine) row `step % u_cap` of a ring with one column per sequence
+    const float u = u_buf ? (step_counter ? u_buf[(size_t)(step_counter[0] % u_cap) * u_stride + blockIdx.x] : *u_buf) : u_val;
     const double thr = (double)u * (double)total;
     if (tid == 0) { owner = SMP_THREADS; last_kept = -1; }
     __syncthreads();
@@ -234,6 +236,15 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const T* logits_all
         });
         out[blockIdx.x] = pick;
     }
+}
+
+// engine entry: fp32 logits rows, uniforms from a device ring indexed by the engine's step counter
+pgk_status sample_rows_ring(const float* logits, int rows, int vocab, float temperature, int top_k, float top_p, const float* u_ring,
+                            int u_cap, int u_stride, const int32_t* step_counter, int32_t* out, hipStream_t st) {
+    PGK_REQUIRE(logits && u_ring && step_counter && out && u_cap > 0, "sample_rows_ring: sampling state not set up");
+    sample_kernel<float><<<rows, SMP_THREADS, 0, st>>>(logits, vocab, temperature, top_k, top_p, 0.f, u_ring, out, step_counter, u_cap, u_stride);
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
 }
 
 }  // namespace pgk

@@ -85,6 +85,24 @@ class Engine:
             raise ValueError("set_state: tokens and positions must have the same length")
         _hip.call("pgk_engine_set_state", self.handle, t.ctypes.data_as(_hip.c_i32_p), p.ctypes.data_as(_hip.c_i32_p), len(t), None)
 
+    def set_sampling(self, temperature: float, top_k: int = 0, top_p: float = 1.0, uniforms: np.ndarray | None = None,
+                     n_steps: int = 256, seed: int | None = None) -> np.ndarray | None:
+        """Switch the decode step from greedy argmax to a temperature / top-k / top-p draw made inside the step (and so
+        inside a captured graph).  `uniforms` [n_steps, max_batch] float32 in [0,1) (drawn from `seed` when omitted) are
+        queued on the device: step s uses row s % n_steps.  Returns the uniforms used (None when switching back to
+        greedy with temperature <= 0).  Call before capture(); call again to queue fresh uniforms."""
+        if temperature <= 0:
+            _hip.call("pgk_engine_set_sampling", self.handle, C.c_float(0.0), 0, C.c_float(1.0), None, 0, None)
+            return None
+        if uniforms is None:
+            uniforms = np.random.default_rng(seed).random((n_steps, self.max_batch), dtype=np.float32)
+        u = np.ascontiguousarray(uniforms, dtype=np.float32)
+        if u.ndim != 2 or u.shape[1] != self.max_batch:
+            raise ValueError(f"set_sampling: uniforms must be [n_steps, {self.max_batch}]")
+        _hip.call("pgk_engine_set_sampling", self.handle, C.c_float(temperature), int(top_k), C.c_float(top_p),
+                  u.ctypes.data_as(C.POINTER(C.c_float)), u.shape[0], None)
+        return u
+
     def decode_step(self, batch: int = 1) -> None:
         """Enqueue one eager (un-captured) step."""
         _hip.call("pgk_engine_decode_step", self.handle, batch, None)

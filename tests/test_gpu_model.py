@@ -355,3 +355,43 @@ def test_config5_width_prefill_is_consistent_across_chunkings(fmt):
     eng.prefill(toks[:2048], want_last_logits=False)
     two = eng.prefill(toks[2048:], start_pos=2048).copy()
     assert np.isfinite(one).all() and rel_err(two, one) < 1e-2, rel_err(two, one)
+
+
+def test_engine_in_graph_sampling_matches_oracle_sampler(tiny_weights):
+    """Stochastic decode inside the captured whole-step graph: every step draws from the step's logits with the queued
+    uniform number.  Replayed against the oracle: feed the oracle model the engine's own token history, apply
+    sample_token_u with the same u, and require the same token wherever the draw is not within 3e-3 (of the kept mass) of a boundary
+    (the engine's bf16 logits differ from the oracle's fp32 ones by ~1e-3 relative)."""
+    B, T, k, p, steps = 2, 0.8, 40, 0.95, 6
+    prompts = [[5, 100, 7, 900], [33, 2]]
+    eng = S.build_engine_from_weights(TINY, tiny_weights, max_seq_len=64, max_batch=B)
+    u = eng.set_sampling(T, top_k=k, top_p=p, n_steps=steps, seed=123)
+    first = [int(np.argmax(eng.prefill(pr, seq=b))) for b, pr in enumerate(prompts)]
+    eng.set_state(first, [len(pr) for pr in prompts])
+    eng.capture(B)
+    eng.replay(steps)
+    eng.synchronize()
+    toks = eng.read_tokens(B, steps)                          # [steps, B]
+    ref = O.build_qwen3_ref(TINY, tiny_weights, max_pos=64)
+    checked = 0
+    for b in range(B):
+        hist = prompts[b] + [first[b]]
+        for s_ in range(steps):
+            hid, _ = ref(hist)
+            lg = ref.get_logits(hid)[-1]
+            want, margin_ = O.sample_token_u(lg, T, k, p, float(u[s_, b]), return_margin=True)
+            if margin_ > 3e-3:
+                assert int(toks[s_, b]) == want, (b, s_)
+                checked += 1
+            hist.append(int(toks[s_, b]))                     # follow the engine's own history
+    assert checked >= steps                                    # most draws are away from a boundary
+    # greedy again after switching sampling off (re-capture: the sampling node is part of the graph)
+    eng.set_sampling(0.0)
+    eng.set_state(first, [len(pr) for pr in prompts])
+    eng.capture(B)
+    eng.replay(2)
+    eng.synchronize()
+    g = eng.read_tokens(B, steps + 2)[-2:]
+    for b in range(B):
+        hid, _ = ref(prompts[b] + [first[b]])
+        assert int(g[0, b]) == int(np.argmax(ref.get_logits(hid)[-1])) or margin(ref.get_logits(hid)[-1]) < 0.02

@@ -197,3 +197,35 @@ class Engine:
                 self.decode_step(1)
         self.synchronize()
         return out + [int(t) for t in self.read_tokens(1, n)[:, 0]]
+
+    def generate(self, prompt, max_new_tokens: int, temperature: float = 1.0, top_k: int = 50, top_p: float = 0.9, *,
+                 seed: int | None = None) -> list[int]:
+        """CausalTransformerModel.generate's sampling semantics (causal.py:179-255) with every draw made on the device:
+        the first token from the prefill logits (ops.sample_token_gpu semantics via the oracle-restated sampler), the
+        rest inside the captured decode graph (set_sampling).  temperature == 0 is generate_greedy."""
+        if temperature == 0:
+            return self.generate_greedy(prompt, max_new_tokens)
+        from pygpukit_amd.core.factory import from_numpy
+        from pygpukit_amd.ops.sampling import sample_token_gpu
+
+        prompt = [int(t) for t in prompt]
+        rng = np.random.default_rng(seed)
+        logits = self.prefill(prompt, seq=0, start_pos=0)
+        first = sample_token_gpu(from_numpy(np.ascontiguousarray(logits, dtype=np.float32)), temperature, top_k, top_p,
+                                 u=float(rng.random(dtype=np.float32)))
+        out = prompt + [first]
+        n = max_new_tokens - 1
+        if n <= 0:
+            return out[: len(prompt) + max_new_tokens]
+        self.reset_log()
+        u = np.zeros((n, self.max_batch), np.float32)
+        u[:, 0] = rng.random(n, dtype=np.float32)
+        self.set_sampling(temperature, top_k, top_p, uniforms=u)
+        self.set_state([first], [len(prompt)])
+        self.capture(1)            # the sampling node is part of the graph
+        self.replay(n)
+        self.synchronize()
+        toks = [int(t) for t in self.read_tokens(1, n)[:, 0]]
+        self.set_sampling(0.0)
+        self._captured_batch = None
+        return out + toks

@@ -395,3 +395,14 @@ def test_engine_in_graph_sampling_matches_oracle_sampler(tiny_weights):
     for b in range(B):
         hid, _ = ref(prompts[b] + [first[b]])
         assert int(g[0, b]) == int(np.argmax(ref.get_logits(hid)[-1])) or margin(ref.get_logits(hid)[-1]) < 0.02
+
+
+def test_engine_generate_with_sampling_is_reproducible_and_diverse(tiny_weights):
+    eng = S.build_engine_from_weights(TINY, tiny_weights, max_seq_len=64, max_batch=1)
+    a = eng.generate([1, 2, 3], 12, temperature=1.0, top_k=50, top_p=0.9, seed=4)
+    b = eng.generate([1, 2, 3], 12, temperature=1.0, top_k=50, top_p=0.9, seed=4)
+    c = eng.generate([1, 2, 3], 12, temperature=1.0, top_k=50, top_p=0.9, seed=5)
+    g = eng.generate([1, 2, 3], 12, temperature=0.0)
+    assert a == b and len(a) == 15 and a[:3] == [1, 2, 3]
+    assert a != c                                              # another seed, another continuation
+    assert g == eng.generate_greedy([1, 2, 3], 12)             # greedy restored after sampling was switched off

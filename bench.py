@@ -99,6 +99,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--long-prefill", type=int, default=2048,
                     help="also time a prefill of this many tokens (the MFMA-bound regime); 0 = skip")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra legs (batch 8 per GPU; context 2048 in bf16 and w8a16) reported under 'extras'")
     ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (result is then INVALID)")
     args = ap.parse_args()
 
@@ -269,6 +271,29 @@ def main() -> None:
                    "runs_ms": [round(x, 3) for x in l_ms]}
         del eng_l
 
+    # ---- extra legs: the other single-GPU BASELINE configs at the same weights (reported, not the headline) ----
+    extras = None
+    if not args.no_extras and cp.world == 1 and B == 1 and args.weight_format == "bf16" and P == 128:
+        def decode_leg(fmt, batch, prompt_len, steps=32, warm=4):
+            e2 = S.build_engine_from_weights(cfg, weights, max_seq_len=prompt_len + steps + warm + 8, max_batch=batch, weight_format=fmt)
+            pr = np.random.default_rng(3000 + args.seed).integers(0, cfg["vocab_size"], (batch, prompt_len))
+            f0 = [int(np.argmax(e2.prefill([int(t) for t in pr[b]], seq=b))) for b in range(batch)]
+            e2.set_state(f0, [prompt_len] * batch)
+            e2.capture(batch)
+            e2.replay(warm)
+            _hip.call("pgk_device_sync")
+            t0 = time.perf_counter()
+            e2.replay(steps)
+            _hip.call("pgk_device_sync")
+            dt = time.perf_counter() - t0
+            ab2 = algorithmic_bytes_per_token(cfg, prompt_len + warm + steps // 2, fmt)
+            by = ab2["weights"] + ab2["lm_head"] + batch * (ab2["kv_read"] + ab2["kv_write"] + ab2["logits"])
+            return {"tokens_per_s": batch * steps / dt, "ms_per_step": dt * 1e3 / steps, "batch": batch, "context": prompt_len,
+                    "weights": fmt, "hbm_frac": by / (dt / steps) / 1e9 / HBM_PEAK_GBS}
+        extras = {"config4_per_gpu_batch8": decode_leg("bf16", 8, 128),
+                  "config3_ctx2048_w8a16": decode_leg("fp8", 1, 2048),
+                  "ctx2048_bf16": decode_leg("bf16", 1, 2048)}
+
     # ---- per-kernel timing (eager, event after every kernel) for the roofline objects ----
     prof = eng.profile_step(B, 8)
     ctx_mid = P + W + K // 2
@@ -309,7 +334,7 @@ def main() -> None:
         "roofline": roofline, "step_roofline": step_roofline,
         "prefill": {"ms": pf_med, "tflops": pf_flops / (pf_med * 1e-3) / 1e12, "flops": pf_flops, "logits": "last row only",
                     "frac_mfma_peak": pf_flops / (pf_med * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "runs_ms": [round(x, 3) for x in pf_ms]},
-        "prefill_long": long_pf,
+        "prefill_long": long_pf, "extras": extras,
         "first_tokens": [int(t) for t in tokens[: min(8, len(tokens)), 0]],
         "setup_s": time.perf_counter() - t_setup,
     }

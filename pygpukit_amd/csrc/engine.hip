@@ -446,6 +446,8 @@ struct AttnArgs {
     float* part;          // [B][Hq][nsplit][D+2]
     int nsplit;
     float* attn_direct;   // whole-context variant (nsplit == 1): normalised output [B][Hq][D], no merge launch
+    int* merge_counter;   // split path, in-kernel merge: [B][Hkv] arrival counters (null: separate attn_merge_kernel)
+    float* attn_merged;   //   ... and where the last-arriving workgroup of a kv head writes the merged output [B][Hq][D]
     // fused o_proj path
     const bf16* w_o;      // [H][Hq*D]
     int H, rows_per_block;
@@ -572,6 +574,62 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     } else {
         decode_block_merge<D, G>(st, lds, a.part + (((size_t)b * a.hq + (size_t)kvh * G) * a.nsplit + blockIdx.x) * RS,
                                  (size_t)a.nsplit * RS, lane, wid);
+        if (a.merge_counter) {
+            // In-launch merge (saves the merge kernel and its boundary): publish this slice's records, take a ticket,
+            // and let the workgroup that draws the last ticket of its (sequence, kv head) combine all slices.
+            // Hand-off per the inter-workgroup recipe of the CDNA guide: every storing wave drains its stores, the
+            // workgroup meets, ONE agent-scope release, drain, relaxed ticket; the reducer: ONE agent-scope acquire,
+            // drain, barrier, then plain loads.  Correct for any placement of the slices over XCDs.
+            __shared__ int s_last;
+            __shared__ float w_s[G][64];
+            __shared__ float inv_l[G];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* cnt = a.merge_counter + (size_t)b * a.hkv + kvh;
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int prev = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = prev == a.nsplit - 1;
+            }
+            __syncthreads();
+            if (!s_last) return;
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next layer's launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // same arithmetic, in the same order, as attn_merge_kernel: the two paths are bit-identical
+            const float* hrecs = a.part + ((size_t)b * a.hq + (size_t)kvh * G) * a.nsplit * RS;
+            if (wid < G) {
+                const float* recs = hrecs + (size_t)wid * a.nsplit * RS;
+                const int sc = min(lane, a.nsplit - 1);
+                float m = recs[(size_t)sc * RS], l = recs[(size_t)sc * RS + 1];
+                if (lane >= a.nsplit) { m = -INFINITY; l = 0.f; }
+                const float mx = wave_max(m);
+                const float w = (m == -INFINITY) ? 0.f : __expf(m - mx);
+                const float tot = wave_sum(w * l);
+                w_s[wid][lane] = w;
+                if (lane == 0) inv_l[wid] = tot > 0.f ? 1.0f / tot : 0.f;
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < G * D; e += 256) {
+                const int g = e / D, d = e % D;
+                const float* recs = hrecs + (size_t)g * a.nsplit * RS;
+                float o = 0.f;
+                int s = 0;
+                for (; s + 8 <= a.nsplit; s += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = recs[(size_t)(s + u) * RS + 2 + d];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) o = fmaf(w_s[g][s + u], v[u], o);
+                }
+                for (; s < a.nsplit; ++s) o = fmaf(w_s[g][s], recs[(size_t)s * RS + 2 + d], o);
+                a.attn_merged[((size_t)b * a.hq + (size_t)kvh * G) * D + e] = o * inv_l[g];
+            }
+        }
     }
 }
 
@@ -879,6 +937,7 @@ struct Engine {
     int nsplit = 1, lm_blocks = 1, lm_cap = 1, log_cap = 4096;
     bool batched_mfma = true;   // chunks of 9..16 sequences use engine_batched.cuh (PGK_BATCHED_MFMA=0: GEMV kernels, =2: from 3 up)
     int batched_min = 9;
+    int* merge_cnt = nullptr;      // PGK_ATTN_INKERNEL_MERGE=1: split-KV attention merges inside the launch (last arriver); default: merge kernel
     bool attn_direct_ok = false;
     // in-graph stochastic sampling (pgk_engine_set_sampling): temperature <= 0 keeps greedy argmax
     float sample_temperature = 0.f, sample_top_p = 1.f;
@@ -995,6 +1054,8 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
     // normalised output itself - Hkv * m workgroups, and the merge launch disappears
     const bool direct = !fused && e->attn_direct_ok && m >= 4;
     if (direct) { a.nsplit = 1; a.attn_direct = e->attnv + (size_t)b0 * c.num_heads * D; }
+    const bool inmerge = !fused && !direct && e->merge_cnt != nullptr;
+    if (inmerge) { a.merge_counter = e->merge_cnt + (size_t)b0 * c.num_kv_heads; a.attn_merged = e->attnv + (size_t)b0 * c.num_heads * D; }
     dim3 grid = fused ? dim3(c.hidden_size / e->oproj_rows, c.num_kv_heads, m) : dim3(direct ? 1 : e->nsplit, c.num_kv_heads, m);
 #define PGK_ATTN(GG)                                                               \
     case GG:                                                                       \
@@ -1007,7 +1068,7 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
         default: return set_error(PGK_ERR_UNSUPPORTED, "engine: GQA group %d not in {1,2,4}", G);
     }
 #undef PGK_ATTN
-    if (!fused && !direct) {
+    if (!fused && !direct && !inmerge) {
         attn_merge_kernel<D><<<dim3(c.num_heads, m), D, 0, st>>>(a.part, e->attnv + (size_t)b0 * c.num_heads * D, c.num_heads, e->nsplit);
     }
     PGK_CHECK_HIP(hipGetLastError());
@@ -1059,7 +1120,7 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
             a.res = h; a.out = h; a.ld_out = H;
             if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_PLAIN, EPI_RESID>(a, H, st)) return r;
             mark(KC_OPROJ, st);
-            *launches += (e->attn_direct_ok && M >= 4) ? 1 : 2;   // o_proj (+ the merge kernel unless attention normalised in place)
+            *launches += ((e->attn_direct_ok && M >= 4) || e->merge_cnt) ? 1 : 2;   // o_proj (+ the merge kernel unless attention normalised in place)
         }
         // 4. act = silu(Wg x) * (Wu x), x = rmsnorm(h [+ sum of o_proj partials])
         a = FusedArgs{};
@@ -1152,7 +1213,7 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
         a.res = h; a.out = h; a.ld_out = H;
         if (pgk_status r = launch_batched<WT, PRO_PLAIN, EPI_RESID>(a, M, st)) return r;
         mark(KC_DOWN, st);
-        *launches += (e->attn_direct_ok && M >= 4) ? 5 : 6;
+        *launches += ((e->attn_direct_ok && M >= 4) || e->merge_cnt) ? 5 : 6;
     }
     const int nblk = ceil_div(c.vocab_size, 16) < 2048 ? ceil_div(c.vocab_size, 16) : 2048;
     FusedArgs a{};
@@ -1270,6 +1331,15 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         e->attn_direct_ok = c.max_seq_len <= 512 && !(ed && atoi(ed) == 0);
         e->batched_mfma = !(ev && atoi(ev) == 0) && c.hidden_size % 128 == 0 && c.intermediate_size % 128 == 0 &&
                           (c.num_heads * c.head_dim) % 128 == 0;
+    }
+    {
+        // Off by default: measured at context 2048 the release/acquire hand-off costs more than the kernel boundary it
+        // replaces (attention phase 13.9 us vs 11.4 us with the separate 4.7 us merge kernel; 1118 vs 1240 tok/s).
+        const char* em = getenv("PGK_ATTN_INKERNEL_MERGE");
+        if (em && atoi(em) == 1) {
+            A((void**)&e->merge_cnt, (size_t)B * c.num_kv_heads * 4, &e->ws_bytes);
+            if (e->merge_cnt) PGK_CHECK_HIP(hipMemset(e->merge_cnt, 0, (size_t)B * c.num_kv_heads * 4));
+        }
     }
     A((void**)&e->amax_val, (size_t)B * e->lm_cap * 4, &e->ws_bytes);
     A((void**)&e->amax_idx, (size_t)B * e->lm_cap * 4, &e->ws_bytes);

@@ -406,3 +406,26 @@ def test_engine_generate_with_sampling_is_reproducible_and_diverse(tiny_weights)
     assert a == b and len(a) == 15 and a[:3] == [1, 2, 3]
     assert a != c                                              # another seed, another continuation
     assert g == eng.generate_greedy([1, 2, 3], 12)             # greedy restored after sampling was switched off
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_split_kv_in_launch_merge_is_bit_identical_to_merge_kernel(tiny_weights, B, monkeypatch):
+    """Long-context decode merges the split-KV slices inside the attention launch (the workgroup that draws the last
+    ticket of a kv head combines them, after an agent-scope release / acquire hand-off).  The arithmetic is the merge
+    kernel's, in the same order, so the two paths must agree BIT FOR BIT: 33 slices x 2 layers x 48 steps of hand-offs
+    per sequence, any stale read shows up as a differing logit or token."""
+    rng = np.random.default_rng(70 + B)
+    prompts = [[int(t) for t in rng.integers(0, TINY["vocab_size"], 1500 + 37 * b)] for b in range(B)]
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PGK_ATTN_INKERNEL_MERGE", mode)
+        eng = S.build_engine_from_weights(TINY, tiny_weights, max_seq_len=2112, max_batch=B)
+        first = [int(np.argmax(eng.prefill(p, seq=b))) for b, p in enumerate(prompts)]
+        eng.set_state(first, [len(p) for p in prompts])
+        eng.capture(B)
+        eng.replay(48)
+        eng.synchronize()
+        outs[mode] = (eng.read_tokens(B, 48).copy(), eng.logits(B).to_numpy().copy(), eng.launches_per_step())
+    np.testing.assert_array_equal(outs["1"][0], outs["0"][0])
+    np.testing.assert_array_equal(outs["1"][1], outs["0"][1])
+    assert outs["1"][2] == outs["0"][2] - TINY["num_layers"] * (1 if B == 1 else 2)      # one launch fewer per layer and chunk

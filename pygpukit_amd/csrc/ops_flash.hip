@@ -81,9 +81,20 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
     // Q^T fragments (B operand): lane = query column, k = d
     uint4 qf[KS];
     {
+        // Q is pre-multiplied by scale * log2(e) here (one rounding to 16 bits more, inside the 1e-2 bar): the scores come
+        // out of the MFMA already in the exp2 domain and the per-tile scaling pass (32 multiplies per lane) disappears
         const T* qrow = qh + (size_t)min(qw0 + ql, q_len - 1) * sd.qs + 8 * h;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(qrow + ks * 16);
+        for (int ks = 0; ks < KS; ++ks) {
+            Vec<T> v;
+            v.load(qrow + ks * 16);
+            float f[8];
+            v.to_float(f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] *= scale_log2e;
+            v.from_float(f);
+            qf[ks] = v.raw;
+        }
     }
     f32x16_fl o[DT];
 #pragma unroll
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kvl = (r & 3) + 8 * (r >> 2);
-                float v0 = s0[r] * scale_log2e, v1 = s1[r] * scale_log2e;
+                float v0 = s0[r], v1 = s1[r];
                 if (need_mask) {
                     v0 = kvl <= lim ? v0 : -INFINITY;
                     v1 = 32 + kvl <= lim ? v1 : -INFINITY;
@@ -181,9 +192,13 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
                 mx = fmaxf(mx, fmaxf(v0, v1));
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
+            // Deferred rescale: the reference point of a row only moves when its maximum grew by more than 6 (log2
+            // domain), so probabilities stay <= 64 (exact in fp32 sums, fine in 16-bit P) and on most tiles - for the whole
+            // wave - alpha is exactly 1 and the 64-multiply rescale of O is skipped.
+            const float m_new = (mx > m_run + 6.0f || m_run == -INFINITY) ? fmaxf(m_run, mx) : m_run;
             const float m_use = m_new == -INFINITY ? 0.f : m_new;        // a fully masked row so far: p = exp2(-inf) = 0
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);   // m_run = -inf -> 0 (accumulators are 0 anyway)
+            const bool moved = __builtin_amdgcn_ballot_w64(m_new != m_run) != 0;   // wave-uniform
+            const float alpha = moved ? __builtin_amdgcn_exp2f(m_run - m_use) : 1.0f;   // m_run = -inf -> 0 (accumulators are 0 anyway)
             float ls = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -193,10 +208,12 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
             }
             l_run = l_run * alpha + ls;
             m_run = m_new;
+            if (moved) {
 #pragma unroll
-            for (int i = 0; i < DT; ++i)
+                for (int i = 0; i < DT; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            }
             // ---- O^T += V^T . P^T : 4 k-steps of 16 kv ----
 #pragma unroll
             for (int s = 0; s < 4; ++s) {

@@ -180,17 +180,16 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
             const bool need_mask = kv0 + FL_BKV - 1 > causal_off + qw0 || kv0 + FL_BKV > kv_len;   // wave-uniform
             const int lim = min(causal_off + qw0 + ql, kv_len - 1) - kv0 - 4 * h;                  // local kv row <= lim is visible
             float mx = -INFINITY;
+            if (need_mask) {   // diagonal / ragged tiles only: a real wave-uniform branch, not 32 predicated selects per tile
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kvl = (r & 3) + 8 * (r >> 2);
-                float v0 = s0[r], v1 = s1[r];
-                if (need_mask) {
-                    v0 = kvl <= lim ? v0 : -INFINITY;
-                    v1 = 32 + kvl <= lim ? v1 : -INFINITY;
+                for (int r = 0; r < 16; ++r) {
+                    const int kvl = (r & 3) + 8 * (r >> 2);
+                    s0[r] = kvl <= lim ? s0[r] : -INFINITY;
+                    s1[r] = 32 + kvl <= lim ? s1[r] : -INFINITY;
                 }
-                s0[r] = v0; s1[r] = v1;
-                mx = fmaxf(mx, fmaxf(v0, v1));
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             // Deferred rescale: the reference point of a row only moves when its maximum grew by more than 6 (log2
             // domain), so probabilities stay <= 64 (exact in fp32 sums, fine in 16-bit P) and on most tiles - for the whole

@@ -20,8 +20,13 @@ __device__ __forceinline__ uint16_t f_to_bf16_bits(float f) {
     __bf16 b = static_cast<__bf16>(f);
     return __builtin_bit_cast(uint16_t, b);
 }
+// two floats -> one dword of bf16 (lo in bits 0-15): a 2-wide vector conversion lowers to ONE v_cvt_pk_bf16_f32
+// (RNE, NaN stays NaN); converting the halves separately and OR-ing them costs four instructions
+typedef float pgk_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pgk_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return static_cast<uint32_t>(f_to_bf16_bits(lo)) | (static_cast<uint32_t>(f_to_bf16_bits(hi)) << 16);
+    const pgk_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pgk_bf16x2));
 }
 
 template <class T> __device__ __forceinline__ float to_f(T v);

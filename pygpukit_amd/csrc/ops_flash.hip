@@ -227,8 +227,14 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
                     const int d = i * 32 + ql;
-                    const uint2 lo = *reinterpret_cast<const uint2*>(Vs(buf) + fl_v_off(d, 4 * s + h));
-                    const uint2 hi = *reinterpret_cast<const uint2*>(Vs(buf) + fl_v_off(d, 4 * s + 2 + h));
+                    // Each 8-byte read stays a ds_read_b64 (two 32-lane halves, 64-bank modulus - the layout above is
+                    // conflict-free for it).  Left visible, hipcc pairs the reads of tiles i and i+1 into ds_read2st64_b64,
+                    // which is served 16 lanes at a time on a 32-bank modulus: 2-way conflicts, half the rate.
+                    int off_lo = fl_v_off(d, 4 * s + h), off_hi = fl_v_off(d, 4 * s + 2 + h);
+                    asm volatile("" : "+v"(off_lo));
+                    asm volatile("" : "+v"(off_hi));
+                    const uint2 lo = *reinterpret_cast<const uint2*>(Vs(buf) + off_lo);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(Vs(buf) + off_hi);
                     o[i] = mfma32<T>(make_uint4(lo.x, lo.y, hi.x, hi.y), pb, o[i]);
                 }
             }

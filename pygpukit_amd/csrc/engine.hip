@@ -418,13 +418,29 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* amax_val, co
         }
     }
     __syncthreads();
-    for (int b = 0; b < M; ++b) {
-        const bf16* row = embed + (size_t)s_tok[b] * H;
-        for (int i = threadIdx.x; i < H; i += 256) h[(size_t)b * H + i] = to_f(row[i]);
-        for (int i = threadIdx.x; i < half; i += 256) {  // RoPE row of the next position
-            cur_cos[(size_t)b * half + i] = rope_cos[(size_t)s_pos[b] * half + i];
-            cur_sin[(size_t)b * half + i] = rope_sin[(size_t)s_pos[b] * half + i];
+    // next step's inputs for all M sequences in one flat sweep (a loop per sequence paid one memory round trip each:
+    // 24.7 us at M = 8): embedding rows, 8 bf16 per lane, then the RoPE rows of the next positions
+    if ((H & 7) == 0) {
+        const int vpr = H >> 3;
+        for (int idx = threadIdx.x; idx < M * vpr; idx += 256) {
+            const int b = idx / vpr, v = idx - b * vpr;
+            const uint4 raw = *reinterpret_cast<const uint4*>(embed + (size_t)s_tok[b] * H + v * 8);
+            float f[8];
+            WTraits<bf16>::decode(raw, f);
+            float* dst = h + (size_t)b * H + v * 8;
+            *reinterpret_cast<float4*>(dst) = make_float4(f[0], f[1], f[2], f[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(f[4], f[5], f[6], f[7]);
         }
+    } else {
+        for (int idx = threadIdx.x; idx < M * H; idx += 256) {
+            const int b = idx / H;
+            h[idx] = to_f(embed[(size_t)s_tok[b] * H + (idx - b * H)]);
+        }
+    }
+    for (int idx = threadIdx.x; idx < M * half; idx += 256) {
+        const int b = idx / half, i = idx - b * half;
+        cur_cos[idx] = rope_cos[(size_t)s_pos[b] * half + i];
+        cur_sin[idx] = rope_sin[(size_t)s_pos[b] * half + i];
     }
     if (bump && threadIdx.x == 0) step_counter[0] = step + 1;
 }
@@ -944,6 +960,8 @@ struct Engine {
     float sample_temperature = 0.f, sample_top_p = 1.f;
     int sample_top_k = 0, u_cap = 0;
     float* u_ring = nullptr;       // [u_cap][max_batch] uniforms, row = step counter % u_cap
+    void* sample_scratch = nullptr;   // top-k candidate keys (ops_sampling.hip), sized for max_batch rows
+    size_t sample_scratch_cap = 0;
     int32_t* sampled = nullptr;    // [max_batch]   // max_seq <= 512: batch attention in one workgroup per (sequence, kv head)
     int skip_attn = 0;         // PGK_DEBUG_SKIP & 16: do not launch attention at all (timing ablation)
     bool fused_attn = false;   // attn + o_proj in one kernel (short contexts, bf16 W_o)
@@ -1083,13 +1101,14 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
 
 // One decode step for sequences [b0, b0+M); `last` = this is the step's last chunk (bumps the step counter)
 pgk_status sample_rows_ring(const float* logits, int rows, int vocab, float temperature, int top_k, float top_p, const float* u_ring,
-                            int u_cap, int u_stride, const int32_t* step_counter, int32_t* out, hipStream_t st);
+                            int u_cap, int u_stride, const int32_t* step_counter, int32_t* out, void* scratch, hipStream_t st);
+size_t sample_scratch_bytes(int rows, int vocab, int top_k);
 
 // one draw per sequence of the chunk from the fp32 logits the lm_head kernel just wrote; the uniform numbers come from
 // the device ring row (step counter % u_cap), so a captured graph replays with fresh randomness the host queued up
 static pgk_status engine_sample(Engine* e, int b0, int M, hipStream_t st) {
     return sample_rows_ring(e->logits + (size_t)b0 * e->cfg.vocab_size, M, e->cfg.vocab_size, e->sample_temperature, e->sample_top_k,
-                            e->sample_top_p, e->u_ring + b0, e->u_cap, e->cfg.max_batch, e->step_counter, e->sampled + b0, st);
+                            e->sample_top_p, e->u_ring + b0, e->u_cap, e->cfg.max_batch, e->step_counter, e->sampled + b0, e->sample_scratch, st);
 }
 
 template <class WT, class XT, int M>
@@ -1397,6 +1416,7 @@ pgk_status pgk_engine_destroy(pgk_engine eh) {
     if (e->pf_tokens) (void)pgk_free(e->pf_tokens);
     if (e->u_ring) (void)pgk_free(e->u_ring);
     if (e->sampled) (void)pgk_free(e->sampled);
+    if (e->sample_scratch) (void)pgk_free(e->sample_scratch);
     delete e;
     return PGK_OK;
 }
@@ -1693,6 +1713,14 @@ pgk_status pgk_engine_set_sampling(pgk_engine eh, float temperature, int top_k, 
     }
     if (!e->sampled) {
         if (pgk_status r = pgk_malloc((void**)&e->sampled, (size_t)B * 4)) return r;
+    }
+    if (const size_t need = sample_scratch_bytes(B, e->cfg.vocab_size, top_k); need > e->sample_scratch_cap) {
+        PGK_CHECK_HIP(hipStreamSynchronize(st));
+        if (e->sample_scratch) pgk_free(e->sample_scratch);
+        e->sample_scratch = nullptr;
+        e->sample_scratch_cap = 0;
+        if (pgk_status r = pgk_malloc(&e->sample_scratch, need)) return r;
+        e->sample_scratch_cap = need;
     }
     // a shorter refill keeps the ring size (the graph holds u_cap): rows beyond n_rows keep their previous values
     PGK_CHECK_HIP(hipMemcpyAsync(e->u_ring, h_uniforms, (size_t)n_rows * B * 4, hipMemcpyHostToDevice, st));

@@ -18,8 +18,16 @@
 // u comes from the host (value) or from a device buffer (graph-replay compatible, sample_topk_to_buf_ptr).
 // The oracle restates exactly this (oracle/cpu_ref.py sample_token_u).
 //
-// Thresholds are found by an 8-bit-per-pass radix descent on an order-preserving integer image of z, with LDS
-// histograms of counts (top-k) or of integer masses (top-p): 4 passes over the row each, integer atomics only.
+// Thresholds are found by an 8-bit-per-pass radix descent on a 64-bit key: the order-preserving integer image of z in
+// the high word, ~index in the low word.  Keys are unique, so "ties: lowest index first" IS the key order and no tie
+// bookkeeping exists; the low-word passes only run when the threshold bucket still holds more than it needs.
+//
+// Two launch shapes:
+//   * 1 <= top_k <= 1024 (the decode default, top_k = 50): stage 1 cuts the row into 4096-token slices, one workgroup
+//     per slice holds its slice in registers and writes its k best keys; stage 2 (one workgroup per row) selects the
+//     k best of those, and does nucleus cut and draw on <= 1024 survivors in LDS.  ~10 us per draw at V = 151 936.
+//   * otherwise (pure multinomial, or top-p over the whole vocabulary): one 1024-thread workgroup walks the row with
+//     lane-contiguous (coalesced) loads: max, mass descent, indexed draw.
 
 #include "pgk_device.cuh"
 #include "pgk_internal.h"
@@ -27,14 +35,21 @@
 namespace pgk {
 
 constexpr int SMP_THREADS = 1024;
+constexpr int SMP_SLICE_THREADS = 256;
+constexpr int SMP_SLICE_E = 16;                                   // keys a stage-1 thread holds
+constexpr int SMP_SLICE = SMP_SLICE_THREADS * SMP_SLICE_E;        // 4096 tokens per stage-1 workgroup
+constexpr int SMP_MAX_K = 1024;
+
+using u64 = unsigned long long;
 
 __device__ __forceinline__ uint32_t smp_key(float z) {   // larger z -> larger key; -0 < +0 is harmless
     const uint32_t b = __float_as_uint(z);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
-__device__ __forceinline__ unsigned long long smp_mass(float z, float zmax) {
-    return (unsigned long long)((double)expf(z - zmax) * 4294967296.0);
-}
+__device__ __forceinline__ float smp_unkey(uint32_t k) { return (k & 0x80000000u) ? __uint_as_float(k & 0x7fffffffu) : __uint_as_float(~k); }
+__device__ __forceinline__ u64 smp_key64(float z, int i) { return ((u64)smp_key(z) << 32) | (uint32_t)~(uint32_t)i; }
+__device__ __forceinline__ int smp_index(u64 key) { return (int)~(uint32_t)key; }
+__device__ __forceinline__ u64 smp_mass(float z, float zmax) { return (u64)((double)expf(z - zmax) * 4294967296.0); }
 
 // block-wide exclusive scan of one value per thread (1024 threads); returns this thread's base, *total gets the sum
 template <class V>
@@ -59,26 +74,227 @@ __device__ __forceinline__ V smp_scan(V v, V* wave_tot /* [17] */, V* total) {
     return wave_tot[wid] + inc - v;
 }
 
+struct SmpSel {
+    u64 remaining, weight;
+    int bucket;
+    unsigned cnt;
+};
+
+// wave 0: walk the 256 buckets from the top and pick the one in which the running weight reaches `remaining`
+// (bucket 0 if none does).  Four buckets per lane, one shuffle scan.
+__device__ __forceinline__ void smp_pick(const u64* hist, const unsigned* cnt, u64 remaining, SmpSel* sh) {
+    const int lane = threadIdx.x;
+    u64 h[4], loc = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { h[q] = hist[255 - (lane * 4 + q)]; loc += h[q]; }
+    u64 inc = loc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    const u64 m = __ballot(inc >= remaining);
+    const int L = m ? __ffsll((long long)m) - 1 : 63;
+    if (lane == L) {
+        u64 acc = inc - loc;
+        int q = 0;
+        for (; q < 3; ++q) {
+            if (m && acc + h[q] >= remaining) break;
+            acc += h[q];
+        }
+        const int b = 255 - (lane * 4 + q);
+        sh->bucket = b;
+        sh->remaining = remaining - acc;
+        sh->weight = h[q];
+        sh->cnt = cnt ? cnt[b] : 0u;
+    }
+}
+
+// Radix descent over this workgroup's keys.  for_each(g) must call g(key, weight_fn) once per live key of the calling
+// thread.  Returns T such that {key >= T} is the smallest top set whose weight reaches `target`
+// (MASS = false: weight 1 per key, i.e. the `target` largest keys; MASS = true: integer masses).
+template <bool MASS, class FE>
+__device__ __forceinline__ u64 smp_select(FE&& for_each, u64 target, u64* hist, unsigned* cnt, SmpSel* sh) {
+    u64 prefix = 0, mask = 0, remaining = target;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+            hist[t] = 0;
+            if (MASS) cnt[t] = 0;
+        }
+        __syncthreads();
+        for_each([&](u64 key, auto&& weight) {
+            if ((key & mask) == prefix) {
+                const int b = (int)(key >> shift) & 255;
+                if (MASS) {
+                    atomicAdd(&hist[b], weight());
+                    atomicAdd(&cnt[b], 1u);
+                } else {
+                    atomicAdd(&hist[b], 1ull);
+                }
+            }
+        });
+        __syncthreads();
+        if (threadIdx.x < 64) smp_pick(hist, MASS ? cnt : nullptr, remaining, sh);
+        __syncthreads();
+        prefix |= (u64)sh->bucket << shift;
+        mask |= 255ull << shift;
+        remaining = sh->remaining;
+        // the whole bucket is needed (counts) / the bucket is one key (masses): every lower bit may stay 0
+        if (MASS ? sh->cnt == 1u : sh->weight == remaining) break;
+    }
+    return prefix;
+}
+
+__device__ __forceinline__ float smp_u(float u_val, const float* u_buf, const int32_t* step_counter, int u_cap, int u_stride, int row) {
+    // a host value, one device float shared by the rows, or (engine) row `step % u_cap` of a ring with one column per sequence
+    return u_buf ? (step_counter ? u_buf[(size_t)(step_counter[0] % u_cap) * u_stride + row] : *u_buf) : u_val;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// top-k path, stage 1: the k best keys of one 4096-token slice
+// ---------------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(SMP_SLICE_THREADS) void sample_slice_topk_kernel(const T* logits_all, int V, float temperature, int k,
+                                                                              u64* cand /* [rows][slices][k] */) {
+    __shared__ u64 hist[256];
+    __shared__ SmpSel sh;
+    __shared__ int out_pos;
+    const int tid = threadIdx.x, slice = blockIdx.x, row = blockIdx.y;
+    const T* logits = logits_all + (size_t)row * V;
+    const int lo = slice * SMP_SLICE, n = min(V - lo, SMP_SLICE);
+    u64 key[SMP_SLICE_E];
+#pragma unroll
+    for (int j = 0; j < SMP_SLICE_E; ++j) {
+        const int o = tid + SMP_SLICE_THREADS * j;
+        key[j] = o < n ? smp_key64(to_f(logits[lo + o]) / temperature, lo + o) : 0ull;
+    }
+    u64 T64 = 0;
+    if (n > k) {
+        T64 = smp_select<false>(
+            [&](auto&& g) {
+#pragma unroll
+                for (int j = 0; j < SMP_SLICE_E; ++j)
+                    if (key[j]) g(key[j], [] { return 1ull; });
+            },
+            (u64)k, hist, nullptr, &sh);
+    }
+    if (tid == 0) out_pos = 0;
+    __syncthreads();
+    u64* dst = cand + ((size_t)row * gridDim.x + slice) * k;
+#pragma unroll
+    for (int j = 0; j < SMP_SLICE_E; ++j)
+        if (key[j] && key[j] >= T64) dst[atomicAdd(&out_pos, 1)] = key[j];
+    __syncthreads();
+    for (int p = out_pos + tid; p < k; p += SMP_SLICE_THREADS) dst[p] = 0ull;
+}
+
+// stage 2: the k best of the slices' candidates, then nucleus cut and draw on those k keys in LDS
+__global__ __launch_bounds__(SMP_THREADS) void sample_topk_draw_kernel(const u64* cand_all, int n /* slices*k */, int k, float top_p, float u_val,
+                                                                       const float* u_buf, int32_t* out, const int32_t* step_counter, int u_cap,
+                                                                       int u_stride) {
+    __shared__ u64 hist[256];
+    __shared__ SmpSel sh;
+    __shared__ u64 tot64[17];
+    __shared__ u64 ka[SMP_MAX_K], kb[SMP_MAX_K], ma[SMP_MAX_K], mb[SMP_MAX_K];
+    __shared__ int nk_s, cut_s, pick_s;
+    __shared__ u64 top_s;
+    const int tid = threadIdx.x, row = blockIdx.x;
+    const u64* cand = cand_all + (size_t)row * n;
+
+    u64 T64 = 0;
+    if (n > k) {
+        T64 = smp_select<false>(
+            [&](auto&& g) {
+                for (int i = tid; i < n; i += SMP_THREADS) {
+                    const u64 key = cand[i];
+                    if (key) g(key, [] { return 1ull; });
+                }
+            },
+            (u64)k, hist, nullptr, &sh);
+    }
+    if (tid == 0) { nk_s = 0; top_s = 0; cut_s = SMP_MAX_K; pick_s = SMP_MAX_K; }
+    __syncthreads();
+    for (int i = tid; i < n; i += SMP_THREADS) {
+        const u64 key = cand[i];
+        if (key && key >= T64) {
+            ka[atomicAdd(&nk_s, 1)] = key;
+            atomicMax(&top_s, key);
+        }
+    }
+    __syncthreads();
+    int nk = nk_s;                                  // == k (k < V is the caller's precondition)
+    const float zmax = smp_unkey((uint32_t)(top_s >> 32));
+    const u64 mykey = tid < nk ? ka[tid] : 0ull;
+    const u64 mymass = tid < nk ? smp_mass(smp_unkey((uint32_t)(mykey >> 32)), zmax) : 0ull;
+
+    if (top_p < 1.0f) {
+        // order by key descending (rank by counting: keys are unique), cut at the smallest prefix reaching top_p * S
+        if (tid < nk) {
+            int r = 0;
+            for (int i = 0; i < nk; ++i) r += ka[i] > mykey;
+            kb[r] = mykey;
+            mb[r] = mymass;
+        }
+        __syncthreads();
+        const u64 m = tid < nk ? mb[tid] : 0ull;
+        u64 S;
+        const u64 base = smp_scan<u64>(m, tot64, &S);
+        const double want = (double)top_p * (double)S;
+        u64 remaining = (u64)want;
+        if ((double)remaining < want) ++remaining;      // ceil
+        if (remaining < 1) remaining = 1;
+        if (tid < nk && base + m >= remaining) atomicMin(&cut_s, tid);
+        __syncthreads();
+        nk = min(nk, cut_s + 1);
+    } else {
+        if (tid < nk) { kb[tid] = mykey; mb[tid] = mymass; }
+        __syncthreads();
+    }
+    // ascending index order == descending low word
+    const u64 key2 = tid < nk ? kb[tid] : 0ull;
+    const u64 mass2 = tid < nk ? mb[tid] : 0ull;
+    if (tid < nk) {
+        const uint32_t lw = (uint32_t)key2;
+        int r = 0;
+        for (int i = 0; i < nk; ++i) r += (uint32_t)kb[i] > lw;
+        ka[r] = key2;
+        ma[r] = mass2;
+    }
+    __syncthreads();
+    const u64 m = tid < nk ? ma[tid] : 0ull;
+    u64 total;
+    const u64 base = smp_scan<u64>(m, tot64, &total);
+    const double thr = (double)smp_u(u_val, u_buf, step_counter, u_cap, u_stride, row) * (double)total;
+    if (tid < nk && (double)(base + m) >= thr) atomicMin(&pick_s, tid);
+    __syncthreads();
+    if (tid == 0) out[row] = smp_index(ka[pick_s < nk ? pick_s : nk - 1]);   // u >= 1 and rounding: the last kept token
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// whole-row path: one workgroup per row
+// ---------------------------------------------------------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const T* logits_all, int V, float temperature, int top_k, float top_p,
                                                             float u_val, const float* u_buf, int32_t* out, const int32_t* step_counter = nullptr,
                                                             int u_cap = 0, int u_stride = 0) {
-    __shared__ unsigned long long hist[256];
-    __shared__ unsigned long long tot64[17];
-    __shared__ int tot32[17];
+    __shared__ u64 hist[256];
+    __shared__ unsigned cnt[256];
+    __shared__ SmpSel sh;
+    __shared__ u64 tot64[17];
     __shared__ float red[16];
-    __shared__ unsigned long long sel_remaining;
-    __shared__ int sel_bucket, owner, last_kept;
+    __shared__ u64 wmass[16];
+    __shared__ int wlast[16];
+    __shared__ int pick_s;
 
     const T* logits = logits_all + (size_t)blockIdx.x * V;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int chunk = (V + SMP_THREADS - 1) / SMP_THREADS;
-    const int lo = min(tid * chunk, V), hi = min(lo + chunk, V);
     auto Z = [&](int i) { return to_f(logits[i]) / temperature; };
 
     // ---- 1. max ----
     float mx = -INFINITY;
-    for (int i = lo; i < hi; ++i) mx = fmaxf(mx, Z(i));
+#pragma unroll 8
+    for (int i = tid; i < V; i += SMP_THREADS) mx = fmaxf(mx, Z(i));
     mx = wave_max(mx);
     if (lane == 0) red[wid] = mx;
     __syncthreads();
@@ -86,163 +302,133 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const T* logits_all
 #pragma unroll
     for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
 
-    // radix descent: select the key T such that the weights of keys > T sum to < target <= including T.
-    // weight(i, rank-aware) is supplied by the caller; returns T and what is still needed from the ties at T.
-    uint32_t Tk = 0;            // top-k threshold key (0: everything passes)
-    int need_k = 0x7fffffff;    // ties at Tk that are kept (in index order)
-    int tie_base_k = 0;
-    const bool use_k = top_k > 0 && top_k < V;
-    if (use_k) {
-        uint32_t prefix = 0, mask = 0;
-        unsigned long long remaining = (unsigned long long)top_k;
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
-            for (int i = lo; i < hi; ++i) {
-                const uint32_t key = smp_key(Z(i));
-                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1ull);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                unsigned long long acc = 0;
-                int b = 255;
-                for (; b > 0; --b) {
-                    if (acc + hist[b] >= remaining) break;
-                    acc += hist[b];
-                }
-                sel_bucket = b;
-                sel_remaining = remaining - acc;
-            }
-            __syncthreads();
-            prefix |= (uint32_t)sel_bucket << shift;
-            mask |= 255u << shift;
-            remaining = sel_remaining;
-            __syncthreads();
-        }
-        Tk = prefix;
-        need_k = (int)remaining;
-        int ties = 0;
-        for (int i = lo; i < hi; ++i) ties += smp_key(Z(i)) == Tk;
-        int tt;
-        tie_base_k = smp_scan<int>(ties, tot32, &tt);
+    // ---- 2. top-k threshold (k > 1024 or k >= V never reaches the sliced path) ----
+    u64 Tk = 0;
+    if (top_k > 0 && top_k < V) {
+        Tk = smp_select<false>(
+            [&](auto&& g) {
+                for (int i = tid; i < V; i += SMP_THREADS) g(smp_key64(Z(i), i), [] { return 1ull; });
+            },
+            (u64)top_k, hist, nullptr, &sh);
     }
-    // kept-by-k predicate needs the running tie rank: walk the chunk in index order
-    auto for_each_k = [&](auto&& f) {   // f(i, z, key) for every element top-k keeps
-        int rank = tie_base_k;
-        for (int i = lo; i < hi; ++i) {
-            const float z = Z(i);
-            const uint32_t key = smp_key(z);
-            bool keep = key > Tk;
-            if (key == Tk) { keep = rank < need_k; ++rank; }
-            if (!use_k) keep = true;
-            if (keep) f(i, z, key);
-        }
-    };
 
     // ---- 3. nucleus threshold inside what top-k kept ----
-    uint32_t Tf = Tk;
-    int need_f = need_k;
-    bool use_f = use_k;          // a final threshold exists
+    u64 Tf = Tk;
     if (top_p < 1.0f) {
-        unsigned long long mine = 0;
-        for_each_k([&](int, float z, uint32_t) { mine += smp_mass(z, mx); });
-        unsigned long long S;
-        smp_scan<unsigned long long>(mine, tot64, &S);
+        u64 mine = 0;
+#pragma unroll 8
+        for (int i = tid; i < V; i += SMP_THREADS) {
+            const float z = Z(i);
+            if (smp_key64(z, i) >= Tk) mine += smp_mass(z, mx);
+        }
+        u64 S;
+        smp_scan<u64>(mine, tot64, &S);
         const double want = (double)top_p * (double)S;
-        unsigned long long remaining = (unsigned long long)want;
+        u64 remaining = (u64)want;
         if ((double)remaining < want) ++remaining;      // ceil
         if (remaining < 1) remaining = 1;
-        uint32_t prefix = 0, mask = 0;
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
-            for_each_k([&](int, float z, uint32_t key) {
-                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], smp_mass(z, mx));
-            });
-            __syncthreads();
-            if (tid == 0) {
-                unsigned long long acc = 0;
-                int b = 255;
-                for (; b > 0; --b) {
-                    if (acc + hist[b] >= remaining) break;
-                    acc += hist[b];
+        Tf = smp_select<true>(
+            [&](auto&& g) {
+                for (int i = tid; i < V; i += SMP_THREADS) {
+                    const float z = Z(i);
+                    const u64 key = smp_key64(z, i);
+                    if (key >= Tk) g(key, [&] { return smp_mass(z, mx); });
                 }
-                sel_bucket = b;
-                sel_remaining = remaining - acc;
-            }
-            __syncthreads();
-            prefix |= (uint32_t)sel_bucket << shift;
-            mask |= 255u << shift;
-            remaining = sel_remaining;
-            __syncthreads();
-        }
-        Tf = prefix;
-        // every tie at Tf carries the same mass: how many of them reach the target
-        const float zt = (Tf & 0x80000000u) ? __uint_as_float(Tf & 0x7fffffffu) : __uint_as_float(~Tf);
-        const unsigned long long qt = smp_mass(zt, mx);
-        unsigned long long n = qt ? (remaining + qt - 1) / qt : 0x7fffffffull;
-        if (n < 1) n = 1;
-        if (n > 0x7fffffffull) n = 0x7fffffffull;
-        need_f = (int)n;
-        if (use_k && Tf == Tk && need_f > need_k) need_f = need_k;
-        use_f = true;
+            },
+            remaining, hist, cnt, &sh);
     }
 
-    // ---- 4. final kept set, its mass, the draw ----
-    int tie_base_f = 0;
-    if (use_f) {
-        int ties = 0;
-        for (int i = lo; i < hi; ++i) ties += smp_key(Z(i)) == Tf;
-        int tt;
-        tie_base_f = smp_scan<int>(ties, tot32, &tt);
-    }
-    auto for_each_final = [&](auto&& f) {
-        int rank = tie_base_f;
-        for (int i = lo; i < hi; ++i) {
-            const float z = Z(i);
-            const uint32_t key = smp_key(z);
-            bool keep = key > Tf;
-            if (key == Tf) { keep = rank < need_f; ++rank; }
-            if (!use_f) keep = true;
-            if (keep) f(i, z);
-        }
-    };
-    unsigned long long mine = 0;
+    // ---- 4. the draw, in ascending index order: wave w owns one contiguous 1/16 of the row, 64 tokens per step ----
+    const int per_wave = ((V + 15) / 16 + 63) & ~63;
+    const int wlo = min(wid * per_wave, V), whi = min(wlo + per_wave, V);
+    u64 mine = 0;
     int my_last = -1;
-    for_each_final([&](int i, float z) { mine += smp_mass(z, mx); my_last = i; });
-    unsigned long long total;
-    const unsigned long long base = smp_scan<unsigned long long>(mine, tot64, &total);
-    // u: a host value, one device float shared by the rows, or (engine) row `step % u_cap` of a ring with one column per sequence
-    const float u = u_buf ? (step_counter ? u_buf[(size_t)(step_counter[0] % u_cap) * u_stride + blockIdx.x] : *u_buf) : u_val;
-    const double thr = (double)u * (double)total;
-    if (tid == 0) { owner = SMP_THREADS; last_kept = -1; }
+#pragma unroll 8
+    for (int i = wlo + lane; i < whi; i += 64) {
+        const float z = Z(i);
+        if (smp_key64(z, i) >= Tf) { mine += smp_mass(z, mx); my_last = i; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mine += __shfl_xor(mine, d, 64);
+        my_last = max(my_last, __shfl_xor(my_last, d, 64));
+    }
+    if (lane == 0) { wmass[wid] = mine; wlast[wid] = my_last; }
+    if (tid == 0) pick_s = -1;
     __syncthreads();
-    if (my_last >= 0) {
-        atomicMax(&last_kept, my_last);
-        if ((double)(base + mine) >= thr) atomicMin(&owner, tid);
+    u64 total = 0, base = 0;
+    int last_kept = -1;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        if (w < wid) base += wmass[w];
+        total += wmass[w];
+        last_kept = max(last_kept, wlast[w]);
+    }
+    const double thr = (double)smp_u(u_val, u_buf, step_counter, u_cap, u_stride, blockIdx.x) * (double)total;
+    // the owner is the first wave that keeps something and whose inclusive mass reaches thr
+    bool earlier = false;
+    {
+        u64 b = 0;
+        for (int w = 0; w < wid; ++w) {
+            b += wmass[w];
+            earlier |= wlast[w] >= 0 && (double)b >= thr;
+        }
+    }
+    if (!earlier && my_last >= 0 && (double)(base + mine) >= thr) {
+        u64 cum = base;
+        for (int i0 = wlo; i0 < whi; i0 += 64) {
+            const int i = i0 + lane;
+            bool keep = false;
+            u64 m = 0;
+            if (i < whi) {
+                const float z = Z(i);
+                keep = smp_key64(z, i) >= Tf;
+                if (keep) m = smp_mass(z, mx);
+            }
+            u64 inc = m;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const u64 o = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += o;
+            }
+            const u64 hit = __ballot(keep && (double)(cum + inc) >= thr);
+            if (hit) {
+                if (lane == 0) pick_s = i0 + __ffsll((long long)hit) - 1;
+                break;
+            }
+            cum += __shfl(inc, 63, 64);
+        }
     }
     __syncthreads();
-    if (owner == SMP_THREADS) {            // u >= 1 and rounding: the last kept token (sampling_kernels.cuh:257)
-        if (tid == 0) out[blockIdx.x] = last_kept >= 0 ? last_kept : V - 1;
-        return;
-    }
-    if (tid == owner) {
-        unsigned long long cum = base;
-        int pick = my_last;
-        bool done = false;
-        for_each_final([&](int i, float z) {
-            cum += smp_mass(z, mx);
-            if (!done && (double)cum >= thr) { pick = i; done = true; }
-        });
-        out[blockIdx.x] = pick;
+    if (tid == 0) out[blockIdx.x] = pick_s >= 0 ? pick_s : (last_kept >= 0 ? last_kept : V - 1);   // u >= 1 and rounding
+}
+
+static inline bool smp_sliced(int top_k, int vocab) { return top_k >= 1 && top_k <= SMP_MAX_K && top_k < vocab; }
+static inline int smp_slices(int vocab) { return (vocab + SMP_SLICE - 1) / SMP_SLICE; }
+
+size_t sample_scratch_bytes(int rows, int vocab, int top_k) {
+    return smp_sliced(top_k, vocab) ? (size_t)rows * smp_slices(vocab) * top_k * sizeof(u64) : 0;
+}
+
+template <class T>
+static void sample_launch(const T* logits, int rows, int vocab, float temperature, int top_k, float top_p, float u, const float* u_buf,
+                          const int32_t* step_counter, int u_cap, int u_stride, int32_t* out, void* scratch, hipStream_t st) {
+    if (smp_sliced(top_k, vocab) && scratch) {
+        const int slices = smp_slices(vocab);
+        sample_slice_topk_kernel<T><<<dim3(slices, rows), SMP_SLICE_THREADS, 0, st>>>(logits, vocab, temperature, top_k, (u64*)scratch);
+        sample_topk_draw_kernel<<<rows, SMP_THREADS, 0, st>>>((const u64*)scratch, slices * top_k, top_k, top_p, u, u_buf, out, step_counter,
+                                                              u_cap, u_stride);
+    } else {
+        sample_kernel<T><<<rows, SMP_THREADS, 0, st>>>(logits, vocab, temperature, top_k, top_p, u, u_buf, out, step_counter, u_cap, u_stride);
     }
 }
 
-// engine entry: fp32 logits rows, uniforms from a device ring indexed by the engine's step counter
+// engine entry: fp32 logits rows, uniforms from a device ring indexed by the engine's step counter.  `scratch`
+// (sample_scratch_bytes) lets 1 <= top_k <= 1024 take the sliced path; without it the whole-row kernel runs.
 pgk_status sample_rows_ring(const float* logits, int rows, int vocab, float temperature, int top_k, float top_p, const float* u_ring,
-                            int u_cap, int u_stride, const int32_t* step_counter, int32_t* out, hipStream_t st) {
+                            int u_cap, int u_stride, const int32_t* step_counter, int32_t* out, void* scratch, hipStream_t st) {
     PGK_REQUIRE(logits && u_ring && step_counter && out && u_cap > 0, "sample_rows_ring: sampling state not set up");
-    sample_kernel<float><<<rows, SMP_THREADS, 0, st>>>(logits, vocab, temperature, top_k, top_p, 0.f, u_ring, out, step_counter, u_cap, u_stride);
+    sample_launch<float>(logits, rows, vocab, temperature, top_k, top_p, 0.f, u_ring, step_counter, u_cap, u_stride, out, scratch, st);
     PGK_CHECK_HIP(hipGetLastError());
     return PGK_OK;
 }
@@ -261,8 +447,16 @@ pgk_status pgk_sample_token(const void* logits, int rows, int vocab, pgk_dtype d
     PGK_REQUIRE(top_k >= 0 && top_p > 0.f && top_p <= 1.f, "pgk_sample_token: need top_k >= 0 and 0 < top_p <= 1 (got %d, %g)", top_k, (double)top_p);
     PGK_REQUIRE(u_buf || (u >= 0.f && u <= 1.f), "pgk_sample_token: u=%g outside [0,1]", (double)u);
     hipStream_t st = resolve_stream(s);
+    // the sliced top-k path needs a candidate buffer; a capturing stream cannot allocate, so a captured launch
+    // (sample_topk_to_buf_ptr inside a user graph) takes the whole-row kernel.  The engine brings its own buffer.
+    void* scratch = nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    PGK_CHECK_HIP(hipStreamIsCapturing(st, &cap));
+    if (const size_t bytes = sample_scratch_bytes(rows, vocab, top_k); bytes && cap == hipStreamCaptureStatusNone)
+        if (pgk_status r = pgk_malloc(&scratch, bytes)) return r;
     PGK_DISPATCH_FLOAT(dt, "pgk_sample_token",
-                       (sample_kernel<T><<<rows, SMP_THREADS, 0, st>>>((const T*)logits, vocab, temperature, top_k, top_p, u, u_buf, out_tokens)));
+                       (sample_launch<T>((const T*)logits, rows, vocab, temperature, top_k, top_p, u, u_buf, nullptr, 0, 0, out_tokens, scratch, st)));
+    if (scratch) pgk_free(scratch);   // stream-ordered reuse
     PGK_LAUNCH_CHECK();
     return PGK_OK;
 }

@@ -71,6 +71,40 @@ def build_model_from_weights(cfg: dict, weights: dict, *, dtype: str = "bfloat16
                                   QWEN3_SPEC)
 
 
+def build_gpt2_from_weights(cfg: dict, weights: dict, *, dtype: str = "float32", biases: dict | None = None):
+    """CausalTransformerModel (GPT-2 style: learned positions, LayerNorm, GELU MLP, no RoPE) on the GPU from the
+    weight dict of BASELINE config 1 ({"wte", "wpe", "layers": [{q,k,v,o,fc1,fc2}]}); LayerNorm gamma=1, beta=0.
+    `biases` (optional, {"q","k","v","o","fc1","fc2"} -> per-layer list of vectors) adds Linear biases, which the
+    reference's CPU path cannot run but real GPT-2 checkpoints carry."""
+    from pygpukit_amd.llm.config import GPT2_SPEC, TransformerConfig
+    from pygpukit_amd.llm.layers import MLP, Attention, Norm, TransformerBlock
+    from pygpukit_amd.llm.models.causal import CausalTransformerModel
+
+    def W(x):
+        return _bf16(x) if dtype == "bfloat16" else from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+
+    H, eps = cfg["hidden_size"], cfg["norm_eps"]
+    c = TransformerConfig(vocab_size=cfg["vocab_size"], hidden_size=H, num_layers=cfg["num_layers"], num_heads=cfg["num_heads"],
+                          num_kv_heads=cfg["num_kv_heads"], intermediate_size=cfg["intermediate_size"], _head_dim=cfg["head_dim"],
+                          norm_type="layernorm", activation="gelu", use_rope=False, causal=True,
+                          max_position_embeddings=cfg["max_position_embeddings"], norm_eps=eps)
+    one, zero = np.ones(H, np.float32), np.zeros(H, np.float32)
+
+    def ln():
+        return Norm(W(one), W(zero), "layernorm", eps)
+
+    def B(name, i):
+        return W(biases[name][i]) if biases else None
+
+    blocks = []
+    for i, lw in enumerate(weights["layers"]):
+        attn = Attention(W(lw["q"]), W(lw["k"]), W(lw["v"]), W(lw["o"]), c, q_bias=B("q", i), k_bias=B("k", i), v_bias=B("v", i),
+                         o_bias=B("o", i))
+        mlp = MLP(c, fc1_weight=W(lw["fc1"]), fc1_bias=B("fc1", i), fc2_weight=W(lw["fc2"]), fc2_bias=B("fc2", i))
+        blocks.append(TransformerBlock(ln(), attn, ln(), mlp))
+    return CausalTransformerModel(c, W(weights["wte"]), blocks, ln(), None, W(weights["wpe"]), GPT2_SPEC)
+
+
 def make_qwen3_weights(cfg: dict, seed: int = 0, std: float = 0.02) -> dict:
     """Same generator as oracle.cpu_ref.make_qwen3_weights (kept here so bench.py's GPU leg does not import
     the oracle): N(0, std^2) float32 draws in the order embed, then per layer q,k,v,o,gate,up,down, each

@@ -727,6 +727,35 @@ def test_sample_token_gpu_matches_oracle(dt, params):
         assert ops.sample_token_gpu(d, T, k, p, u=u) == O.sample_token_u(lg, T, k, p, u)
 
 
+@pytest.mark.parametrize("V", [4095, 4096, 4097, 8192 + 5, 40000])
+@pytest.mark.parametrize("k", [1, 7, 1024, 1025])
+def test_sample_sliced_topk_boundaries(V, k):
+    """1 <= top_k <= 1024 runs the sliced two-stage kernels (4096-token slices), above that the whole-row kernel:
+    slice edges, a ragged last slice, heavy ties (a quantised row: ~60 distinct values) and several rows per call
+    all give the oracle's token."""
+    if k >= V:
+        pytest.skip("top_k >= vocab keeps everything")
+    rng = np.random.default_rng(V * 31 + k)
+    rows = 3
+    lg = (np.round(rng.standard_normal((rows, V)) * 8) / 4).astype(np.float32)        # many exact ties
+    lg[:, V - 1] = lg.max() + 0.25                                                     # the last token is in every top-k
+    d = dev(lg)
+    res = pk.empty((rows,), "int32")
+    for p_ in (1.0, 0.8):
+        for _ in range(3):
+            u = float(np.float32(rng.random()))
+            ub = from_numpy(np.array([u], np.float32))
+            if p_ == 1.0:
+                ops.sample_topk_to_buf_ptr(d, res, ub, k, 1.0)      # all rows in one launch, u from device memory
+            for r in range(rows):
+                tok, margin = O.sample_token_u(lg[r], 1.0, k, p_, u, return_margin=True)
+                if margin <= 1e-4:
+                    continue
+                if p_ == 1.0:
+                    assert res.to_numpy()[r] == tok, (V, k, r, u)
+                assert ops.sample_token_gpu(dev(lg[r]), 1.0, k, p_, u=u) == tok, (V, k, p_, r, u)
+
+
 def test_sample_ties_and_small_vocab():
     """Ties at the top-k / nucleus boundary are kept lowest-index-first; tiny rows (V < threads) work."""
     lg = np.array([1.0, 3.0, 3.0, 3.0, 0.5, 3.0, -2.0], np.float32)

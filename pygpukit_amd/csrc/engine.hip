@@ -761,8 +761,12 @@ __global__ void embed_rows_kernel(const bf16* embed, const int32_t* tokens, floa
 // h32[s] += sum of the split-K slabs of the projection that precedes this norm (if any), written back;
 // x_bf16[s] = rmsnorm(h32[s]) * gamma.  One 256-thread workgroup per row, 4 elements per thread per trip;
 // the slab loads are unconditional (clamped slab index, masked add) so they share one memory round trip.
+// With q8 != nullptr (fp8-activation prefill, H % 128 == 0) the row leaves as e4m3 codes + one fp32 scale per 128
+// columns instead of bf16: the values quantised are the bf16-rounded ones, so this is bit-identical to
+// rmsnorm -> quantize_rows_kernel without the second pass over the activations.
 __global__ __launch_bounds__(256) void rmsnorm_f32_bf16_kernel(float* h, const bf16* gamma, bf16* out, int rows, int H,
-                                                               float eps, const float* slabs, int nslabs) {
+                                                               float eps, const float* slabs, int nslabs,
+                                                               uint8_t* q8 = nullptr, float* q8s = nullptr) {
     __shared__ float red[16];
     const int row = blockIdx.x;
     float* hr = h + (size_t)row * H;
@@ -803,7 +807,18 @@ __global__ __launch_bounds__(256) void rmsnorm_f32_bf16_kernel(float* h, const b
             uint2 o;
             o.x = pack_bf16x2(v[t].x * inv * g0, v[t].y * inv * g1);
             o.y = pack_bf16x2(v[t].z * inv * g2, v[t].w * inv * g3);
-            *reinterpret_cast<uint2*>(out + (size_t)row * H + i) = o;
+            if (q8) {   // 32 lanes x 4 columns = one 128-column scale block
+                const float f0 = __uint_as_float(o.x << 16), f1 = __uint_as_float(o.x & 0xFFFF0000u);
+                const float f2 = __uint_as_float(o.y << 16), f3 = __uint_as_float(o.y & 0xFFFF0000u);
+                float amax = fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fmaxf(fabsf(f2), fabsf(f3)));
+                amax = group16_max(amax);
+                amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+                const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+                *reinterpret_cast<uint32_t*>(q8 + (size_t)row * H + i) = pack_fp8x4(f0 / sc, f1 / sc, f2 / sc, f3 / sc);
+                if ((threadIdx.x & 31) == 0) q8s[(size_t)row * (H >> 7) + (i >> 7)] = sc;
+            } else {
+                *reinterpret_cast<uint2*>(out + (size_t)row * H + i) = o;
+            }
         }
     }
 }
@@ -883,7 +898,9 @@ __global__ __launch_bounds__(256) void qknorm_rope_kvwrite_kernel(bf16* qkv, con
 
 // act[s][i] = silu(gu[s][i]) * gu[s][I+i]   (bf16 in/out, fp32 math)
 // With nslabs > 0 the gate_up projection arrives as split-K fp32 partials [nslabs][n][2I] (summed, rounded to bf16).
-__global__ void swiglu_rows_kernel(const bf16* gu, bf16* act, int n, int I, const float* slabs, int nslabs) {
+// q8 != nullptr (I % 128 == 0): e4m3 codes + per-(row, 128 columns) scales of the bf16-rounded result instead of bf16
+__global__ void swiglu_rows_kernel(const bf16* gu, bf16* act, int n, int I, const float* slabs, int nslabs, uint8_t* q8 = nullptr,
+                                   float* q8s = nullptr) {
     const size_t total = (size_t)n * I / 8;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += stride) {
@@ -912,7 +929,21 @@ __global__ void swiglu_rows_kernel(const bf16* gu, bf16* act, int n, int I, cons
 #pragma unroll
         for (int j = 0; j < 8; ++j) gf[j] = gf[j] / (1.0f + __expf(-gf[j])) * uf[j];
         g.from_float(gf);
-        g.store(act + s * I + c * 8);
+        if (q8) {   // 16 lanes x 8 columns = one scale block; total and stride are multiples of 16, so groups stay whole
+            g.to_float(gf);
+            float amax = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(gf[j]));
+            amax = group16_max(amax);
+            const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+            uint2 o;
+            o.x = pack_fp8x4(gf[0] / sc, gf[1] / sc, gf[2] / sc, gf[3] / sc);
+            o.y = pack_fp8x4(gf[4] / sc, gf[5] / sc, gf[6] / sc, gf[7] / sc);
+            *reinterpret_cast<uint2*>(q8 + s * I + c * 8) = o;
+            if ((c & 15) == 0) q8s[s * (I >> 7) + (c >> 4)] = sc;
+        } else {
+            g.store(act + s * I + c * 8);
+        }
     }
 }
 
@@ -1479,9 +1510,15 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     uint8_t* q8 = (uint8_t*)(((uintptr_t)slabs + (ws ? slab_elems * 4 : 0) + 255) & ~(uintptr_t)255);   // fp8 activations [n][maxk]
     float* q8s = (float*)(q8 + (size_t)n * maxk);                                                          // their scales [n][maxk/128]
     int pending = 0;   // split-K slabs of the previous projection still to be added into h32 by the next norm
+    // fp8act: RMSNorm and SwiGLU leave their result in q8/q8s themselves (x_in == nullptr); attention output is
+    // quantised here (its rows span all heads, a flash workgroup only sees one)
+    // (PGK_FP8_FUSED_QUANT=0 keeps the separate quantise pass: the A/B switch of the bit-identity test)
+    const char* fq_env = getenv("PGK_FP8_FUSED_QUANT");
+    const bool fuse_q = fp8act && H % 128 == 0 && I % 128 == 0 && H <= 4096 && !(fq_env && atoi(fq_env) == 0);
     auto proj_accum = [&](const bf16* x_in, const void* w, const void* sc, int N_, int K_, int splits) -> pgk_status {
         if (fp8act) {
-            if (pgk_status r = quantize_fp8_rows_bf16(x_in, q8, q8s, n, K_, st)) return r;
+            if (x_in)
+                if (pgk_status r = quantize_fp8_rows_bf16(x_in, q8, q8s, n, K_, st)) return r;
             return gemm_fp8_nt(q8, q8s, (const uint8_t*)w, (const bf16*)sc, h32, true, n, N_, K_, st);
         }
         if (!ws) return engine_gemm_nt(x_in, w, (const bf16*)sc, fp8, h32, true, n, N_, K_, st);
@@ -1492,15 +1529,17 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     // with splits > 1 the result is left as fp32 split-K slabs for the consumer kernel to sum
     auto proj_store = [&](const bf16* x_in, const void* w, const void* sc, bf16* out_, int N_, int K_, int splits) -> pgk_status {
         if (fp8act) {
-            if (pgk_status r = quantize_fp8_rows_bf16(x_in, q8, q8s, n, K_, st)) return r;
+            if (x_in)
+                if (pgk_status r = quantize_fp8_rows_bf16(x_in, q8, q8s, n, K_, st)) return r;
             return gemm_fp8_nt(q8, q8s, (const uint8_t*)w, (const bf16*)sc, out_, false, n, N_, K_, st);
         }
         if (!ws) return engine_gemm_nt(x_in, w, (const bf16*)sc, fp8, out_, false, n, N_, K_, st);
         if (splits > 1) return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, slabs, nullptr, 1, splits, n, N_, K_, st);
         return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, out_, nullptr, 0, 1, n, N_, K_, st);
     };
-    auto norm = [&](const bf16* gamma) -> pgk_status {
-        rmsnorm_f32_bf16_kernel<<<n, 256, 0, st>>>(h32, gamma, x, n, H, c.norm_eps, slabs, pending);
+    auto norm = [&](const bf16* gamma, bool to_fp8 = false) -> pgk_status {
+        rmsnorm_f32_bf16_kernel<<<n, 256, 0, st>>>(h32, gamma, x, n, H, c.norm_eps, slabs, pending, to_fp8 ? q8 : nullptr,
+                                                   to_fp8 ? q8s : nullptr);
         pending = 0;
         PGK_LAUNCH_CHECK();
         return PGK_OK;
@@ -1512,8 +1551,8 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
         const auto& L = e->layers[l];
         bf16* kc = e->kcache + (size_t)l * e->kv_layer_elems() + (size_t)seq * c.num_kv_heads * c.max_seq_len * D;
         bf16* vc = e->vcache + (size_t)l * e->kv_layer_elems() + (size_t)seq * c.num_kv_heads * c.max_seq_len * D;
-        if (pgk_status r = norm((const bf16*)L.attn_norm)) return r;
-        if (pgk_status r = proj_store(x, L.w_qkv, L.s_qkv, qkv, NQKV, H, s_qkv)) return r;
+        if (pgk_status r = norm((const bf16*)L.attn_norm, fuse_q)) return r;
+        if (pgk_status r = proj_store(fuse_q ? nullptr : x, L.w_qkv, L.s_qkv, qkv, NQKV, H, s_qkv)) return r;
         {
             const int nslots = c.num_heads + 2 * c.num_kv_heads;
             const bf16* qg = c.use_qk_norm ? (const bf16*)L.q_norm : nullptr;
@@ -1532,11 +1571,12 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
                                            (int64_t)c.max_seq_len * D, D, D, QD, PGK_BF16, st))
             return r;
         if (pgk_status r = proj_accum(attn, L.w_o, L.s_o, H, QD, s_o)) return r;
-        if (pgk_status r = norm((const bf16*)L.mlp_norm)) return r;
-        if (pgk_status r = proj_store(x, L.w_gate_up, L.s_gate_up, gu, 2 * I, H, s_gu)) return r;
-        swiglu_rows_kernel<<<ceil_div((long long)n * I / 8, 256) > 2048 ? 2048 : ceil_div((long long)n * I / 8, 256), 256, 0, st>>>(gu, act, n, I, slabs, s_gu > 1 ? s_gu : 0);
+        if (pgk_status r = norm((const bf16*)L.mlp_norm, fuse_q)) return r;
+        if (pgk_status r = proj_store(fuse_q ? nullptr : x, L.w_gate_up, L.s_gate_up, gu, 2 * I, H, s_gu)) return r;
+        swiglu_rows_kernel<<<ceil_div((long long)n * I / 8, 256) > 2048 ? 2048 : ceil_div((long long)n * I / 8, 256), 256, 0, st>>>(
+            gu, act, n, I, slabs, s_gu > 1 ? s_gu : 0, fuse_q ? q8 : nullptr, fuse_q ? q8s : nullptr);
         PGK_LAUNCH_CHECK();
-        if (pgk_status r = proj_accum(act, L.w_down, L.s_down, H, I, s_d)) return r;
+        if (pgk_status r = proj_accum(fuse_q ? nullptr : act, L.w_down, L.s_down, H, I, s_d)) return r;
     }
     if (pgk_status r = norm(e->final_norm)) return r;
     if (all_logits) {

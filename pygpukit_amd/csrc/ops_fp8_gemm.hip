@@ -136,12 +136,7 @@ __global__ __launch_bounds__(F8_THREADS) void gemm_fp8_kernel(const uint8_t* A, 
 }
 
 // ---- quantisers --------------------------------------------------------------------------------
-// RNE f32 -> e4m3 pair packing: v_cvt_pk_fp8_f32 (OCP on gfx950)
-__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
-    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-    return (uint32_t)w;
-}
+// (pack_fp8x4: RNE f32 -> e4m3, pgk_device.cuh)
 
 // Activations: one scale per row per 128 k.  16 lanes x 8 elements cover one (row, block); scale = absmax/448
 // (1 when the block is all zero), codes = RNE(x / scale).

@@ -114,6 +114,12 @@ __device__ __forceinline__ float group16_sum(float v) {
     v += dpp_f<DPP_MIRROR>(v);
     return v;
 }
+// RNE f32 -> OCP e4m3, four codes per dword: v_cvt_pk_fp8_f32 (OCP encoding on gfx950)
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+}
 __device__ __forceinline__ float group16_max(float v) {
     v = fmaxf(v, dpp_f<DPP_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_XOR2>(v));
     v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v)); v = fmaxf(v, dpp_f<DPP_MIRROR>(v));

@@ -335,10 +335,17 @@ static pgk_status launch_mfma(const T* A, const void* B, const bf16* bscale, con
 template <class T, int MODE, int EPI = 0>
 static pgk_status dispatch_mfma(const T* A, const void* B, const bf16* bscale, const T* bias, void* C, int M, int N, int K,
                                 hipStream_t st) {
-    const int bm = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
-    const long long mblocks = (M + bm - 1) / bm;
+    int bm = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
+    long long mblocks = (M + bm - 1) / bm;
     int bn = 128;
     while (bn > 32 && mblocks * ((N + bn - 1) / bn) < 256) bn >>= 1;
+    // 128 x 64 tiles that only just cover the chip (one 4-wave workgroup per CU, nothing to overlap its barriers with)
+    // lose to twice as many 64 x 64 tiles: M=2048, N=1024, K=2048/3072 measured 23.9 / 33.9 us against 28.3 / 39.9
+    if (bm == 128 && bn == 64 && mblocks * ((N + 63) / 64) < 512) { bm = 64; mblocks = (M + 63) / 64; }
+    if (const char* e = getenv("PGK_GEMM_TILE")) {   // experiments: "bm,bn"
+        int a_ = 0, b_ = 0;
+        if (sscanf(e, "%d,%d", &a_, &b_) == 2) { bm = a_; bn = b_; }
+    }
     if (MODE == B_KN_FP8 && bn < 64) bn = 64;  // keep whole 16-code chunks per thread
 #define PGK_TILE(BM_, BN_) if (bm == BM_ && bn == BN_) return launch_mfma<T, BM_, BN_, MODE, EPI>(A, B, bscale, bias, C, M, N, K, st);
     PGK_TILE(128, 128) PGK_TILE(128, 64) PGK_TILE(128, 32)

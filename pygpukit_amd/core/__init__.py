@@ -6,12 +6,14 @@ from pygpukit_amd.core.backend import (HipBackend, NativeBackend, device_synchro
 from pygpukit_amd.core.dtypes import (DataType, DataTypeKind, bfloat16, float16, float32, float64, int4, int8, int16,
                                      int32, int64, uint8)
 from pygpukit_amd.core.factory import empty, from_numpy, ones, zeros
-from pygpukit_amd.core.stream import (CudaEvent, CudaGraph, Event, HipGraph, Stream, default_stream, event_elapsed_ms,
-                                     event_elapsed_us, stream_synchronize)
+from pygpukit_amd.core.stream import (CudaEvent, CudaGraph, Event, HipGraph, Stream, StreamManager, StreamPriority,
+                                     current_stream_handle, default_stream, event_elapsed_ms, event_elapsed_us,
+                                     get_stream_manager, stream_synchronize)
 
 __all__ = [
     "GPUArray", "DataType", "DataTypeKind", "float64", "float32", "float16", "bfloat16", "int64", "int32", "int16",
     "int8", "uint8", "int4", "zeros", "ones", "empty", "from_numpy", "get_backend", "HipBackend", "NativeBackend",
     "has_native_module", "get_native_module", "device_synchronize", "Stream", "CudaEvent", "Event", "CudaGraph",
-    "HipGraph", "default_stream", "stream_synchronize", "event_elapsed_ms", "event_elapsed_us",
+    "HipGraph", "default_stream", "stream_synchronize", "event_elapsed_ms", "event_elapsed_us", "StreamManager", "StreamPriority",
+    "get_stream_manager", "current_stream_handle",
 ]

@@ -6,28 +6,63 @@ Stream wrapper src/pygpukit/core/stream.py).  The reference's class names are ke
 from __future__ import annotations
 
 import ctypes as C
+from enum import IntEnum
 
 from pygpukit_amd import _hip
 
 
+class StreamPriority(IntEnum):
+    """core/stream.py:11-15: HIGH is numerically lower, as in the reference."""
+
+    HIGH = 0
+    LOW = 1
+
+
+def _as_priority(priority) -> StreamPriority:
+    if isinstance(priority, str):
+        return StreamPriority.HIGH if priority.lower() == "high" else StreamPriority.LOW
+    if priority is True:
+        return StreamPriority.HIGH
+    return StreamPriority(int(priority))
+
+
 class Stream:
-    def __init__(self, priority: str | int = "low") -> None:
-        _hip.require_device()
-        h = C.c_void_p()
-        high = 1 if priority in ("high", 1, True) else 0
-        _hip.call("pgk_stream_create", C.byref(h), high)
-        self._h = h.value
-        self.priority = "high" if high else "low"
+    """A hipStream with the reference's Python Stream surface (core/stream.py:18-52): `handle`, `priority`,
+    `synchronize()`, repr naming the priority.  `Stream(handle, priority)` wraps an existing stream as the reference's
+    constructor does; `Stream()` / `Stream("high")` / `Stream(priority=...)` creates one (the native `Stream(priority)`
+    of core_bindings.cpp:208-230).  Used as a context manager it becomes the calling thread's current stream, which every
+    op without an explicit stream argument launches on."""
+
+    def __init__(self, stream_handle=None, priority: str | int | StreamPriority = StreamPriority.LOW) -> None:
+        if isinstance(stream_handle, (str, StreamPriority)) or stream_handle is True:   # Stream("high")
+            stream_handle, priority = None, stream_handle
+        self._priority = _as_priority(priority)
+        self._owns = stream_handle is None
+        if stream_handle is None:
+            _hip.require_device()
+            h = C.c_void_p()
+            _hip.call("pgk_stream_create", C.byref(h), 1 if self._priority == StreamPriority.HIGH else 0)
+            stream_handle = h.value
+        self._h = stream_handle
 
     @property
     def handle(self) -> int:
         return self._h
+
+    @property
+    def priority(self) -> StreamPriority:
+        return self._priority
 
     def synchronize(self) -> None:
         _hip.call("pgk_stream_sync", C.c_void_p(self._h))
 
     def make_current(self) -> None:
         _hip.call("pgk_stream_set_current", C.c_void_p(self._h))
+
+    def destroy(self) -> None:
+        if self._h and self._owns:
+            _hip.call("pgk_stream_destroy", C.c_void_p(self._h))
+        self._h = 0
 
     def __enter__(self):
         self.make_current()
@@ -37,20 +72,74 @@ class Stream:
         _hip.call("pgk_stream_set_current", None)
         return False
 
+    def __repr__(self) -> str:
+        return f"Stream(priority={'HIGH' if self._priority == StreamPriority.HIGH else 'LOW'})"
+
     def __del__(self):
         try:
-            if self._h:
-                _hip.call("pgk_stream_destroy", C.c_void_p(self._h))
+            self.destroy()
         except Exception:
             pass
-        self._h = 0
 
 
-def default_stream() -> int:
-    """Handle of the calling thread's current stream."""
+class StreamManager:
+    """core/stream.py:55-122: creates, tracks and destroys streams; one lazily created LOW-priority default stream."""
+
+    def __init__(self) -> None:
+        self._streams: list[Stream] = []
+        self._default_stream: Stream | None = None
+
+    def create_stream(self, priority: str | StreamPriority = "low") -> Stream:
+        stream = Stream(None, _as_priority(priority))
+        self._streams.append(stream)
+        return stream
+
+    def destroy_stream(self, stream: Stream) -> None:
+        if stream in self._streams:
+            self._streams.remove(stream)
+            if stream is self._default_stream:
+                self._default_stream = None
+            stream.destroy()
+
+    def get_default_stream(self) -> Stream:
+        if self._default_stream is None:
+            self._default_stream = self.create_stream(StreamPriority.LOW)
+        return self._default_stream
+
+    def synchronize_all(self) -> None:
+        for stream in self._streams:
+            stream.synchronize()
+
+    def __del__(self) -> None:
+        for stream in getattr(self, "_streams", []):
+            try:
+                stream.destroy()
+            except Exception:
+                pass
+        self._streams = []
+
+
+_stream_manager: StreamManager | None = None
+
+
+def get_stream_manager() -> StreamManager:
+    global _stream_manager
+    if _stream_manager is None:
+        _stream_manager = StreamManager()
+    return _stream_manager
+
+
+def default_stream() -> Stream:
+    """core/stream.py:133-135: the global manager's default stream (a Stream object)."""
+    return get_stream_manager().get_default_stream()
+
+
+def current_stream_handle() -> int:
+    """Handle of the stream ops launch on when given none: the innermost `with stream:` of this thread, the graph
+    capture stream while capturing, else the library's own non-blocking default stream."""
     h = C.c_void_p()
     _hip.call("pgk_stream_get_current", C.byref(h))
-    return h.value
+    return h.value or 0
 
 
 def stream_synchronize(handle: int | None = None) -> None:

@@ -133,6 +133,20 @@ pgk_status pgk_binary_inplace(void* a, const void* b, size_t n, int op, pgk_dtyp
 pgk_status pgk_bias_add_inplace(void* out, const void* bias, int rows, int features, pgk_dtype dt, pgk_stream s);
 /* ops.cuh:136 gelu (tanh form 0.7978845608/0.044715), :176-179 silu; act: 0 silu, 1 gelu, 2 sigmoid, 3 tanh, 4 relu2 */
 pgk_status pgk_activation(const void* x, void* y, size_t n, int act, pgk_dtype dt, pgk_stream s);
+/* ... and the unary family of ops.cuh:60-101 (src/pygpukit/ops/unary.py:16-260) through the same entry:
+ * act 5 exp, 6 log, 7 relu, 8 sin, 9 cos, 10 sqrt, 11 rsqrt, 12 abs, 13 neg */
+/* ops.cuh:92-131 (src/pygpukit/ops/reduction.py:16-130,227): whole-array reduction to one element of the input dtype;
+ * op: 0 sum, 1 mean, 2 max, 3 min.  Fixed two-level tree in fp32: the same bits on every run. */
+pgk_status pgk_reduce(const void* x, void* out, size_t n, int op, pgk_dtype dt, pgk_stream s);
+/* reduction.py:133-224 softmax over the last axis of [rows, n] (max-subtracted, fp32 math) */
+pgk_status pgk_softmax_rows(const void* x, void* y, int rows, int n, pgk_dtype dt, pgk_stream s);
+/* reduction.py:271-300 sum_axis of a 2-D [m, n]: axis 0 -> out[n], axis 1 -> out[m] */
+pgk_status pgk_sum_axis(const void* x, void* out, int m, int n, int axis, pgk_dtype dt, pgk_stream s);
+/* ops/elementwise.py:254-276 clamp to [lo, hi]; :279-308 where(cond != 0 ? a : b), cond one byte per element */
+pgk_status pgk_clamp(const void* x, void* y, size_t n, float lo, float hi, pgk_dtype dt, pgk_stream s);
+pgk_status pgk_where(const uint8_t* cond, const void* a, const void* b, void* y, size_t n, pgk_dtype dt, pgk_stream s);
+/* int32 -> int64 (the reference's ops.argmax returns an int64 [1] array, reduction.py:249-268) */
+pgk_status pgk_widen_i32_i64(const int32_t* src, int64_t* dst, size_t n, pgk_stream s);
 /* ops.cuh:206-212 swiglu / geglu: out = act(gate) * up ; act: 0 silu, 1 gelu */
 pgk_status pgk_glu(const void* gate, const void* up, void* out, size_t n, int act, pgk_dtype dt, pgk_stream s);
 /* Row-packed GLU: gate_up[rows, 2*inter] (gate columns then up columns, the fused gate_up projection of

@@ -102,6 +102,45 @@ def gelu(a: np.ndarray) -> np.ndarray:
     return result.astype(a.dtype)
 
 
+# --- the rest of ops.basic (pinned by fixture G6, tests/golden/gen_golden.py gen_basic) ---------------------------
+def unary(name: str, x: np.ndarray) -> np.ndarray:
+    """src/pygpukit/ops/unary.py:38-260 (_exp_cpu ... _neg_cpu) and ops/nn/activation.py sigmoid / tanh / relu2:
+    the NumPy expression each CPU branch evaluates."""
+    f = {"exp": np.exp, "log": np.log, "relu": lambda v: np.maximum(v, 0), "sin": np.sin, "cos": np.cos, "sqrt": np.sqrt,
+         "rsqrt": lambda v: 1.0 / np.sqrt(v), "abs": np.abs, "neg": lambda v: -v,
+         "sigmoid": lambda v: 1.0 / (1.0 + np.exp(-v)), "tanh": np.tanh, "relu2": lambda v: np.maximum(v, 0) ** 2}[name]
+    return f(x).astype(x.dtype)
+
+
+def reduce_all(name: str, x: np.ndarray) -> np.ndarray:
+    """src/pygpukit/ops/reduction.py:38-130,227-268: sum / mean / max / min -> shape [1] in the input dtype;
+    argmax -> int64 [1] (np.argmax: lowest index on ties)."""
+    if name == "argmax":
+        return np.array([np.argmax(x)], dtype=np.int64)
+    return np.array([{"sum": np.sum, "mean": np.mean, "max": np.max, "min": np.min}[name](x)], dtype=x.dtype)
+
+
+def softmax_last(x: np.ndarray) -> np.ndarray:
+    """src/pygpukit/ops/reduction.py:179-185 (_softmax_cpu_nd): max-subtracted softmax over the last axis."""
+    e = np.exp(x - x.max(axis=-1, keepdims=True))
+    return e / e.sum(axis=-1, keepdims=True)
+
+
+def sum_axis(x: np.ndarray, axis: int) -> np.ndarray:
+    """src/pygpukit/ops/reduction.py:298-300."""
+    return np.sum(x, axis=axis)
+
+
+def clamp(x: np.ndarray, lo: float, hi: float) -> np.ndarray:
+    """src/pygpukit/ops/elementwise.py:275-276."""
+    return np.clip(x, lo, hi)
+
+
+def where(cond: np.ndarray, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """src/pygpukit/ops/elementwise.py:305-308."""
+    return np.where(cond.astype(bool), a, b)
+
+
 def swiglu(gate: np.ndarray, up: np.ndarray) -> np.ndarray:
     """[kernel-defined] native/ops/nn/fused_kernels.cuh:36-100: silu(gate) * up, fp32 math."""
     return silu(gate) * up

@@ -65,6 +65,8 @@ _PROTOS = {
     "pgk_graph_num_nodes": [_V, C.POINTER(_Z)], "pgk_graph_destroy": [_V], "pgk_stream_is_capturing": [_V, C.POINTER(_I)],
     "pgk_binary": [_V, _V, _V, _Z, _I, _I, _V], "pgk_binary_inplace": [_V, _V, _Z, _I, _I, _V],
     "pgk_bias_add_inplace": [_V, _V, _I, _I, _I, _V], "pgk_activation": [_V, _V, _Z, _I, _I, _V],
+    "pgk_reduce": [_V, _V, _Z, _I, _I, _V], "pgk_softmax_rows": [_V, _V, _I, _I, _I, _V], "pgk_sum_axis": [_V, _V, _I, _I, _I, _I, _V],
+    "pgk_clamp": [_V, _V, _Z, _F, _F, _I, _V], "pgk_where": [_V, _V, _V, _V, _Z, _I, _V], "pgk_widen_i32_i64": [_V, _V, _Z, _V],
     "pgk_glu": [_V, _V, _V, _Z, _I, _I, _V], "pgk_glu_packed": [_V, _V, _I, _I, _I, _I, _V], "pgk_cast": [_V, _I, _V, _I, _Z, _V],
     "pgk_rmsnorm": [_V, _V, _V, _I, _I, _F, _I, _V], "pgk_rmsnorm_residual": [_V, _V, _V, _V, _I, _I, _F, _I, _V],
     "pgk_layernorm": [_V, _V, _V, _V, _I, _I, _F, _I, _V],

@@ -31,7 +31,17 @@ __device__ __forceinline__ float act_fn(float x, int act) {
         case 1: return x * 0.5f * (1.0f + tanhf(0.7978845608f * (x + 0.044715f * x * x * x)));  // gelu
         case 2: return 1.0f / (1.0f + expf(-x));                                           // sigmoid
         case 3: return tanhf(x);
-        default: { float r = fmaxf(x, 0.f); return r * r; }                                   // relu2
+        case 4: { float r = fmaxf(x, 0.f); return r * r; }                                    // relu2
+        // native/ops/unary (ops.cuh:60-101): exp log relu sin cos sqrt rsqrt abs neg
+        case 5: return expf(x);
+        case 6: return logf(x);
+        case 7: return fmaxf(x, 0.f);
+        case 8: return sinf(x);
+        case 9: return cosf(x);
+        case 10: return sqrtf(x);
+        case 11: return 1.0f / sqrtf(x);
+        case 12: return fabsf(x);
+        default: return -x;
     }
 }
 
@@ -223,7 +233,7 @@ pgk_status pgk_bias_add_inplace(void* out, const void* bias, int rows, int featu
 
 pgk_status pgk_activation(const void* x, void* y, size_t n, int act, pgk_dtype dt, pgk_stream s) {
     PGK_REQUIRE(x && y, "pgk_activation: null pointer");
-    PGK_REQUIRE(act >= 0 && act <= 4, "pgk_activation: bad activation %d", act);
+    PGK_REQUIRE(act >= 0 && act <= 13, "pgk_activation: bad activation %d", act);
     if (!n) return PGK_OK;
     hipStream_t st = resolve_stream(s);
     const bool vec = aligned16(x) && aligned16(y);

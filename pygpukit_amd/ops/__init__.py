@@ -1,6 +1,6 @@
 """pygpukit_amd.ops: operator surface mirroring pygpukit.ops on the LLM-inference hot path."""
 
-from pygpukit_amd.ops.elementwise import add, add_inplace, copy_to, div, mul, mul_inplace, sub
+from pygpukit_amd.ops.elementwise import add, add_inplace, clamp, copy_to, div, mul, mul_inplace, sub, where
 from pygpukit_amd.ops.embedding import (embedding_lookup, embedding_lookup_batch, embedding_lookup_ptr,
                                        kv_cache_prefill_gqa, kv_cache_update_gqa, kv_cache_update_gqa_ptr)
 from pygpukit_amd.ops.matmul import (batched_matmul, gemm_w8a16_init_lut, gemv_bf16, gemv_bf16_opt_available, gemv_fp8_bf16,
@@ -10,7 +10,8 @@ from pygpukit_amd.ops.matmul import (batched_matmul, gemm_w8a16_init_lut, gemv_b
 from pygpukit_amd.ops.nn import (bias_add_inplace, geglu, gelu, glu_packed, layernorm, relu2, rmsnorm, rmsnorm_residual, rope_inplace,
                                 rope_inplace_f32table, sdpa_causal, sdpa_causal_fixed_cache, sdpa_causal_fixed_cache_ptr,
                                 sdpa_causal_strided, sigmoid, silu, slice_rows_range_ptr, split_qkv_batch, swiglu, tanh)
-from pygpukit_amd.ops.reduction import argmax, argmax_rows
+from pygpukit_amd.ops.reduction import argmax, argmax_int, argmax_rows, max, mean, min, softmax, sum, sum_axis
+from pygpukit_amd.ops.unary import abs, cos, exp, log, neg, relu, rsqrt, sin, sqrt
 from pygpukit_amd.ops.paged import (allocate_kv_cache, argmax_sample, check_eos, compute_cumsum, copy_to_paged_cache, gather_embeddings,
                                     paged_attention_v1, prepare_batch_inputs, prepare_position_ids, reshape_and_cache,
                                     scatter_last_token_logits)

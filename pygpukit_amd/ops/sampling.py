@@ -12,7 +12,7 @@ import numpy as np
 from pygpukit_amd.core.array import GPUArray
 from pygpukit_amd.core.dtypes import FLOAT_DTYPES, float32, int32
 from pygpukit_amd.ops._common import call
-from pygpukit_amd.ops.reduction import argmax
+from pygpukit_amd.ops.reduction import argmax_int
 
 _rng = np.random.default_rng()
 
@@ -48,7 +48,7 @@ def _sample(logits: GPUArray, temperature: float, top_k: int, top_p: float, name
 def sample_greedy(logits: GPUArray) -> int:
     """argmax over [vocab] or [1, vocab]; lowest index wins ties (np.argmax), unlike the reference's
     CUDA kernel whose tie-break depends on the thread layout (sampling_kernels.cuh:55-198)."""
-    return argmax(logits)
+    return argmax_int(logits)
 
 
 def sample_multinomial(logits: GPUArray, temperature: float, *, u: float | None = None) -> int:

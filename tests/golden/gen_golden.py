@@ -228,8 +228,36 @@ def gen_qwen3_layer():
     print("g5_qwen3_layer")
 
 
+def gen_basic():
+    """G6: the rest of ops.basic on the reference's NumPy path - unary math, whole-array reductions, softmax,
+    sum_axis, clamp, where, sigmoid / tanh / relu2."""
+    from pygpukit.ops.nn.activation import relu2
+
+    rng = np.random.default_rng(4321)
+    x = (rng.standard_normal((7, 333)) * 2).astype(np.float32)
+    pos = np.abs(x) + np.float32(0.01)
+    out = {"x": x, "pos": pos}
+    for name in ("exp", "relu", "sin", "cos", "abs", "neg", "sigmoid", "tanh"):
+        out[name] = getattr(B, name)(G(x)).to_numpy()
+    out["relu2"] = relu2(G(x)).to_numpy()
+    for name in ("log", "sqrt", "rsqrt"):
+        out[name] = getattr(B, name)(G(pos)).to_numpy()
+    for name in ("sum", "mean", "max", "min", "argmax"):
+        out["red_" + name] = getattr(B, name)(G(x)).to_numpy()
+    out["softmax"] = B.softmax(G(x)).to_numpy()
+    x3 = (rng.standard_normal((2, 3, 50)) * 3).astype(np.float32)
+    out["x3"], out["softmax3"] = x3, B.softmax(G(x3)).to_numpy()
+    out["sum_axis0"], out["sum_axis1"] = B.sum_axis(G(x), 0).to_numpy(), B.sum_axis(G(x), 1).to_numpy()
+    out["clamp"] = B.clamp(G(x), -0.5, 1.25).to_numpy()
+    cond = (rng.random((7, 333)) < 0.4).astype(np.uint8)
+    y = rng.standard_normal((7, 333)).astype(np.float32)
+    out["cond"], out["y"], out["where"] = cond, y, B.where(G(cond), G(x), G(y)).to_numpy()
+    np.savez_compressed(os.path.join(HERE, "g6_basic_ops.npz"), **out)
+    print("g6_basic_ops", len(out))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "fp8", "tiny", "layer", "gpt2"]
+    which = sys.argv[1:] or ["ops", "fp8", "tiny", "layer", "gpt2", "basic"]
     if "ops" in which:
         gen_ops()
     if "fp8" in which:
@@ -240,3 +268,5 @@ if __name__ == "__main__":
         gen_qwen3_layer()
     if "gpt2" in which:
         gen_gpt2_small()
+    if "basic" in which:
+        gen_basic()

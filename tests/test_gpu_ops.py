@@ -55,6 +55,38 @@ def close(a, ref, dt):
 
 
 # ----------------------------------------------------------------------------- runtime
+def test_device_info_and_raw_copies():
+    """core.device / core.memory with the reference's names (device.py:11-120, memory.py:18-215)."""
+    from pygpukit_amd.core import memory as M
+
+    assert pk.is_cuda_available()
+    info = pk.get_device_info(0)
+    assert isinstance(info, pk.DeviceInfo) and info.warp_size == 64 and info.multiprocessor_count >= 64
+    assert info.compute_capability == (9, 5) and info.total_memory > (64 << 30) and info.max_threads_per_block == 1024
+    caps = pk.get_device_capabilities(0)
+    assert caps.sm_version == 950 and caps.tensorcore_bf16 and caps.async_copy and caps.name == info.name
+    free, total = M.get_memory_info()
+    assert 0 < free <= total == info.total_memory
+    src = np.arange(4096, dtype=np.float32)
+    a, b = pk.zeros((4096,)), pk.zeros((4096,))
+    M.copy_to_device(a, src.ctypes.data, src.nbytes)
+    np.testing.assert_array_equal(a.to_numpy(), src)
+    st = pk.Stream()
+    M.copy_to_device_async(b, src.ctypes.data, src.nbytes // 2, st)
+    M.copy_device_to_device_offset(b, src.nbytes // 2, a, 0, src.nbytes // 2)
+    st.synchronize()
+    M.synchronize()
+    np.testing.assert_array_equal(b.to_numpy(), np.concatenate([src[:2048], src[:2048]]))
+    c = pk.zeros((4096,))
+    M.copy_device_to_device_async(c, a, st)
+    st.synchronize()
+    np.testing.assert_array_equal(c.to_numpy(), src)
+    with pytest.raises(ValueError):
+        M.copy_device_to_device_async(pk.zeros((8,)), a, st)
+    with pytest.raises(ValueError):
+        M.copy_to_device(pk.zeros((8,)), src.ctypes.data, src.nbytes)
+
+
 def test_device_is_mi355x_and_pool_works():
     b = pk.get_backend()
     assert b.is_available()
@@ -117,6 +149,61 @@ def test_elementwise_golden_fp32():
     np.testing.assert_allclose(host(ops.gelu(dev(x))), g1["gelu"], rtol=2e-5, atol=2e-6)
     np.testing.assert_array_equal(host(ops.add(dev(x), dev(x[::-1].copy()))), g1["add"])
     np.testing.assert_array_equal(host(ops.mul(dev(x), dev(x[::-1].copy()))), g1["mul"])
+
+
+def test_basic_ops_golden_fp32():
+    """The rest of ops.basic against fixture G6 (outputs of the reference's NumPy path): unary math, whole-array
+    reductions (shape [1], input dtype; argmax int64), softmax 2-D / 3-D, sum_axis, clamp, where."""
+    g6 = load_golden("g6_basic_ops.npz")
+    x, pos = g6["x"], g6["pos"]
+    for name in ("exp", "relu", "sin", "cos", "abs", "neg", "sigmoid", "tanh", "relu2"):
+        np.testing.assert_allclose(host(getattr(ops, name)(dev(x))), g6[name], rtol=3e-6, atol=1e-6, err_msg=name)
+    for name in ("log", "sqrt", "rsqrt"):
+        np.testing.assert_allclose(host(getattr(ops, name)(dev(pos))), g6[name], rtol=3e-6, atol=1e-6, err_msg=name)
+    for name in ("sum", "mean", "max", "min"):
+        got = getattr(ops, name)(dev(x))
+        assert got.shape == (1,) and got.dtype == pk.float32
+        np.testing.assert_allclose(host(got), g6["red_" + name], rtol=2e-5, atol=2e-4, err_msg=name)   # fp32 sums of 2331 terms, another order
+    am = ops.argmax(dev(x))
+    assert am.shape == (1,) and am.dtype == pk.int64
+    np.testing.assert_array_equal(am.to_numpy(), g6["red_argmax"])
+    np.testing.assert_allclose(host(ops.softmax(dev(x))), g6["softmax"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(host(ops.softmax(dev(g6["x3"]))), g6["softmax3"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(host(ops.sum_axis(dev(x), 0)), g6["sum_axis0"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(ops.sum_axis(dev(x), 1)), g6["sum_axis1"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_array_equal(host(ops.clamp(dev(x), -0.5, 1.25)), g6["clamp"])
+    cond = from_numpy(g6["cond"])
+    np.testing.assert_array_equal(host(ops.where(cond, dev(x), dev(g6["y"]))), g6["where"])
+    with pytest.raises(ValueError):
+        ops.softmax(dev(x[0]))
+    with pytest.raises(ValueError):
+        ops.sum_axis(dev(x), 2)
+    with pytest.raises(ValueError):
+        ops.where(cond, dev(x), dev(g6["y"][:3].copy()))
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+def test_basic_ops_half_precision_vs_oracle(dt):
+    """Same ops on 16-bit storage: fp32 math on the rounded inputs, one rounding on the way out; a 1M-element
+    reduction is the same on every run (fixed two-level tree)."""
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal((9, 1000)) * 1.5).astype(np.float32)
+    xr = rounded(x, dt)
+    for name in ("exp", "relu", "sin", "cos", "abs", "neg"):
+        close(host(getattr(ops, name)(dev(x, dt))), O.unary(name, xr), dt)
+    pr = np.abs(xr) + rounded(np.full_like(xr, 0.25), dt)
+    for name in ("log", "sqrt", "rsqrt"):
+        close(host(getattr(ops, name)(dev(pr, dt))), O.unary(name, rounded(pr, dt)), dt)
+    close(host(ops.softmax(dev(x, dt))), O.softmax_last(xr), dt)
+    close(host(ops.sum_axis(dev(x, dt), 1)), O.sum_axis(xr, 1), dt)
+    close(host(ops.clamp(dev(x, dt), -1.0, 0.5)), O.clamp(xr, -1.0, 0.5), dt)
+    assert abs(float(host(ops.max(dev(x, dt)))[0]) - xr.max()) == 0.0 and abs(float(host(ops.min(dev(x, dt)))[0]) - xr.min()) == 0.0
+    big = rng.standard_normal(1 << 20).astype(np.float32)
+    d = dev(big)
+    first = host(ops.sum(d))[0]
+    assert all(host(ops.sum(d))[0] == first for _ in range(3))
+    assert abs(first - big.astype(np.float64).sum()) < 1e-3 * np.sqrt(big.size)
+    assert abs(host(ops.mean(d))[0] - big.mean(dtype=np.float64)) < 1e-5
 
 
 @pytest.mark.parametrize("dt", ["float32", "bfloat16"])
@@ -246,7 +333,7 @@ def test_argmax_lowest_index_ties():
         assert ops.sample_greedy(dev(r, "bfloat16")) == int(np.argmax(O.bf16_round(r)))
     big = np.zeros(151936, np.float32)
     big[[150000, 70000, 1234]] = 5.0
-    assert ops.argmax(dev(big)) == 1234
+    assert int(ops.argmax(dev(big)).to_numpy()[0]) == 1234 and ops.argmax_int(dev(big)) == 1234
     rows = ops.argmax_rows(dev(lg)).to_numpy()
     np.testing.assert_array_equal(rows, np.argmax(lg, axis=1))
     assert ops.sample_token_gpu(dev(lg[0]), 0.0, 0, 1.0) == int(np.argmax(lg[0]))

@@ -237,3 +237,24 @@ def test_paged_attention_oracle_equals_dense_fixed_cache():
     dense = O.sdpa_causal_fixed_cache(q.transpose(1, 0, 2), np.repeat(k.transpose(1, 0, 2), 2, axis=0),
                                       np.repeat(v.transpose(1, 0, 2), 2, axis=0), ctx)
     np.testing.assert_allclose(got[0], dense[:, 0], rtol=2e-5, atol=2e-6)
+
+
+def test_basic_ops_oracle_vs_golden():
+    """G6: unary math, reductions, softmax, sum_axis, clamp, where - the oracle's restatements against the
+    reference's NumPy path (bit-equal: the same NumPy expressions on the same inputs)."""
+    g6 = load_golden("g6_basic_ops.npz")
+    x, pos = g6["x"], g6["pos"]
+    for name in ("exp", "relu", "sin", "cos", "abs", "neg", "sigmoid", "tanh", "relu2"):
+        np.testing.assert_allclose(O.unary(name, x), g6[name], rtol=1e-6, atol=1e-7, err_msg=name)
+    for name in ("log", "sqrt", "rsqrt"):
+        np.testing.assert_allclose(O.unary(name, pos), g6[name], rtol=1e-6, atol=1e-7, err_msg=name)
+    for name in ("sum", "mean", "max", "min", "argmax"):
+        got = O.reduce_all(name, x)
+        assert got.shape == (1,) and got.dtype == g6["red_" + name].dtype
+        np.testing.assert_allclose(got, g6["red_" + name], rtol=1e-6)
+    np.testing.assert_allclose(O.softmax_last(x), g6["softmax"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(O.softmax_last(g6["x3"]), g6["softmax3"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(O.sum_axis(x, 0), g6["sum_axis0"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(O.sum_axis(x, 1), g6["sum_axis1"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(O.clamp(x, -0.5, 1.25), g6["clamp"])
+    np.testing.assert_array_equal(O.where(g6["cond"], x, g6["y"]), g6["where"])

@@ -1133,7 +1133,7 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
 // One decode step for sequences [b0, b0+M); `last` = this is the step's last chunk (bumps the step counter)
 pgk_status sample_rows_ring(const float* logits, int rows, int vocab, float temperature, int top_k, float top_p, const float* u_ring,
                             int u_cap, int u_stride, const int32_t* step_counter, int32_t* out, void* scratch, hipStream_t st);
-size_t sample_scratch_bytes(int rows, int vocab, int top_k);
+size_t sample_scratch_bytes(int rows, int vocab, int top_k, float top_p);
 
 // one draw per sequence of the chunk from the fp32 logits the lm_head kernel just wrote; the uniform numbers come from
 // the device ring row (step counter % u_cap), so a captured graph replays with fresh randomness the host queued up
@@ -1754,7 +1754,7 @@ pgk_status pgk_engine_set_sampling(pgk_engine eh, float temperature, int top_k, 
     if (!e->sampled) {
         if (pgk_status r = pgk_malloc((void**)&e->sampled, (size_t)B * 4)) return r;
     }
-    if (const size_t need = sample_scratch_bytes(B, e->cfg.vocab_size, top_k); need > e->sample_scratch_cap) {
+    if (const size_t need = sample_scratch_bytes(B, e->cfg.vocab_size, top_k, top_p); need > e->sample_scratch_cap) {
         PGK_CHECK_HIP(hipStreamSynchronize(st));
         if (e->sample_scratch) pgk_free(e->sample_scratch);
         e->sample_scratch = nullptr;

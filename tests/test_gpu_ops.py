@@ -843,6 +843,40 @@ def test_sample_sliced_topk_boundaries(V, k):
                 assert ops.sample_token_gpu(dev(lg[r]), 1.0, k, p_, u=u) == tok, (V, k, p_, r, u)
 
 
+def test_sample_whole_vocabulary_sliced_paths():
+    """top_k = 0 on a long row runs sliced: multinomial picks the owning 4096-token slice; a nucleus is cut inside the
+    best 256 keys when they carry top_p of the mass (a peaked, LLM-like row) and falls through to the whole-row kernel
+    when they do not (a flat row).  Three rows in one call - peaked, flat, heavy ties - so both outcomes of the device-side
+    decision happen in the same launch; every token is the oracle's."""
+    import ctypes as C
+
+    from pygpukit_amd import _hip
+
+    rng = np.random.default_rng(91)
+    V = 50000 + 37
+    peaked = (rng.standard_normal(V) * 1.5).astype(np.float32)
+    peaked[rng.integers(0, V, 40)] += rng.uniform(9, 14, 40).astype(np.float32)
+    flat = (rng.standard_normal(V) * 0.5).astype(np.float32)
+    ties = (np.round(rng.standard_normal(V) * 4) / 2).astype(np.float32)
+    lg = np.stack([peaked, flat, ties])
+    d, res = dev(lg), pk.empty((3,), "int32")
+    for T, p_ in ((1.0, 1.0), (0.8, 0.9), (1.0, 0.5), (1.2, 0.999)):
+        for _ in range(4):
+            u = float(np.float32(rng.random()))
+            _hip.call("pgk_sample_token", d._p, 3, V, d.dtype.code, C.c_float(T), 0, C.c_float(p_), C.c_float(u), None, res._p, None)
+            got = res.to_numpy()
+            for r in range(3):
+                tok, margin = O.sample_token_u(lg[r], T, 0, p_, u, return_margin=True)
+                assert margin <= 1e-4 or got[r] == tok, (T, p_, r, u, got[r], tok)
+    # the peaked row's nucleus really is inside its 256 best tokens, the flat row's is not (both branches ran)
+    for row, inside in ((peaked, True), (flat, False)):
+        z = np.sort(row.astype(np.float64) / 0.8)[::-1]
+        pr = np.exp(z - z[0])
+        assert (pr[:256].sum() >= 0.9 * pr.sum()) == inside
+    for u in (0.0, 1.0):
+        assert ops.sample_multinomial(dev(peaked), 1.0, u=u) == O.sample_token_u(peaked, 1.0, 0, 1.0, u)
+
+
 def test_sample_ties_and_small_vocab():
     """Ties at the top-k / nucleus boundary are kept lowest-index-first; tiny rows (V < threads) work."""
     lg = np.array([1.0, 3.0, 3.0, 3.0, 0.5, 3.0, -2.0], np.float32)

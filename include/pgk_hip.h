@@ -178,6 +178,11 @@ pgk_status pgk_rope_inplace(void* q, void* k, const void* cos, const void* sin, 
 pgk_status pgk_transpose_2d(const void* in, void* out, int rows, int cols, int itemsize, pgk_stream s);
 /* ops.cuh:352-354 transpose_3d_021: [d0,d1,d2] -> [d1,d0,d2] */
 pgk_status pgk_transpose_3d_021(const void* in, void* out, int d0, int d1, int d2, int itemsize, pgk_stream s);
+/* src/pygpukit/ops/tensor.py:256-318 transpose_3d_012 ([d0,d1,d2] -> [d0,d2,d1]) and :320-380 transpose_4d_0132
+ * ([d0,d1,d2,d3] -> [d0,d1,d3,d2]): `batch` independent [rows, cols] matrices, each transposed */
+pgk_status pgk_transpose_batched(const void* in, void* out, int batch, int rows, int cols, int itemsize, pgk_stream s);
+/* tensor.py:191-254 transpose_4d_0213: [d0,d1,d2,d3] -> [d0,d2,d1,d3] */
+pgk_status pgk_transpose_4d_0213(const void* in, void* out, int d0, int d1, int d2, int d3, int itemsize, pgk_stream s);
 /* ops.cuh:349 repeat_interleave_axis1: [d0,d1,d2] -> [d0,d1*r,d2] */
 pgk_status pgk_repeat_interleave_axis1(const void* in, void* out, int d0, int d1, int d2, int repeats,
                                        int itemsize, pgk_stream s);

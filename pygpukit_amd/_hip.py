@@ -71,7 +71,7 @@ _PROTOS = {
     "pgk_rmsnorm": [_V, _V, _V, _I, _I, _F, _I, _V], "pgk_rmsnorm_residual": [_V, _V, _V, _V, _I, _I, _F, _I, _V],
     "pgk_layernorm": [_V, _V, _V, _V, _I, _I, _F, _I, _V],
     "pgk_rope_inplace": [_V, _V, _V, _V, _I, _I, _I, _I, _I, _I, _V],
-    "pgk_transpose_2d": [_V, _V, _I, _I, _I, _V], "pgk_transpose_3d_021": [_V, _V, _I, _I, _I, _I, _V],
+    "pgk_transpose_2d": [_V, _V, _I, _I, _I, _V], "pgk_transpose_3d_021": [_V, _V, _I, _I, _I, _I, _V], "pgk_transpose_batched": [_V, _V, _I, _I, _I, _I, _V], "pgk_transpose_4d_0213": [_V, _V, _I, _I, _I, _I, _I, _V],
     "pgk_repeat_interleave_axis1": [_V, _V, _I, _I, _I, _I, _I, _V],
     "pgk_split_qkv_batch": [_V, _V, _V, _V, _I, _I, _I, _I, _I, _V],
     "pgk_embedding_lookup": [_V, _V, _I, _I, _I, _V, _I, _V],

@@ -16,6 +16,8 @@ static inline int cap_grid(size_t items, int block = 256) {
 template <class E>
 __global__ __launch_bounds__(256) void transpose2d_kernel(const E* in, E* out, int rows, int cols) {
     __shared__ E tile[64][65];
+    in += (size_t)blockIdx.z * rows * cols;    // batch of independent [rows, cols] matrices (transpose_3d_012 / 4d_0132)
+    out += (size_t)blockIdx.z * rows * cols;
     const int bx = blockIdx.x * 64, by = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
     for (int r = ty; r < 64; r += 4) {
@@ -177,6 +179,33 @@ pgk_status pgk_transpose_2d(const void* in, void* out, int rows, int cols, int i
         default: return set_error(PGK_ERR_INVALID, "pgk_transpose_2d: itemsize %d", itemsize);
     }
     PGK_LAUNCH_CHECK();
+    return PGK_OK;
+}
+
+pgk_status pgk_transpose_batched(const void* in, void* out, int batch, int rows, int cols, int itemsize, pgk_stream s) {
+    PGK_REQUIRE(in && out, "pgk_transpose_batched: null pointer");
+    PGK_REQUIRE(batch >= 0 && batch <= 65535 && rows >= 0 && cols >= 0, "pgk_transpose_batched: bad shape (batch %d <= 65535)", batch);
+    if (!batch || !rows || !cols) return PGK_OK;
+    hipStream_t st = resolve_stream(s);
+    dim3 grid(ceil_div(cols, 64), ceil_div(rows, 64), batch);
+    switch (itemsize) {
+        case 1: transpose2d_kernel<uint8_t><<<grid, 256, 0, st>>>((const uint8_t*)in, (uint8_t*)out, rows, cols); break;
+        case 2: transpose2d_kernel<uint16_t><<<grid, 256, 0, st>>>((const uint16_t*)in, (uint16_t*)out, rows, cols); break;
+        case 4: transpose2d_kernel<uint32_t><<<grid, 256, 0, st>>>((const uint32_t*)in, (uint32_t*)out, rows, cols); break;
+        case 8: transpose2d_kernel<uint2><<<grid, 256, 0, st>>>((const uint2*)in, (uint2*)out, rows, cols); break;
+        default: return set_error(PGK_ERR_INVALID, "pgk_transpose_batched: itemsize %d", itemsize);
+    }
+    PGK_LAUNCH_CHECK();
+    return PGK_OK;
+}
+
+pgk_status pgk_transpose_4d_0213(const void* in, void* out, int d0, int d1, int d2, int d3, int itemsize, pgk_stream s) {
+    PGK_REQUIRE(in && out, "pgk_transpose_4d_0213: null pointer");
+    if (!d0 || !d1 || !d2 || !d3) return PGK_OK;
+    // each of the d0 slabs is a [d1, d2, d3] -> [d2, d1, d3] row permutation
+    const size_t slab = (size_t)d1 * d2 * d3 * itemsize;
+    for (int b = 0; b < d0; ++b)
+        if (pgk_status r = pgk_transpose_3d_021((const char*)in + b * slab, (char*)out + b * slab, d1, d2, d3, itemsize, s)) return r;
     return PGK_OK;
 }
 

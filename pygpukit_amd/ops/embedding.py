@@ -4,6 +4,8 @@ native/ops/ops.cuh:397-410).  Cache heads may be Hq (the reference's GQA-expande
 
 from __future__ import annotations
 
+import ctypes as C
+
 from pygpukit_amd.core.array import GPUArray
 from pygpukit_amd.core.dtypes import int32
 from pygpukit_amd.ops._common import call, validate_same_dtype
@@ -70,3 +72,24 @@ def kv_cache_prefill_gqa(new_kv: GPUArray, cache: GPUArray, num_heads: int, star
         raise ValueError(f"kv_cache_prefill_gqa: rows {start_pos}..{start_pos + new_kv.shape[0]} outside cache")
     call("pgk_kv_cache_write", new_kv._p, cache._p, new_kv.shape[0], hkv, hc, cache.shape[1], cache.shape[2], cache.itemsize,
          start_pos, None, None)
+
+
+def kv_cache_update(new_kv: GPUArray, cache: GPUArray, position: int) -> None:
+    """new_kv [1, Hkv, D] -> cache[position] of a SEQUENCE-major cache [max_seq, Hkv, D] (embedding.py:78-100;
+    the un-expanded layout, as opposed to kv_cache_update_gqa's [Hq, max_seq, D])."""
+    if new_kv.ndim != 3 or cache.ndim != 3 or new_kv.shape[0] != 1 or new_kv.shape[1:] != cache.shape[1:] or new_kv.dtype != cache.dtype:
+        raise ValueError(f"kv_cache_update: new_kv {new_kv.shape}/{new_kv.dtype} does not fit cache {cache.shape}/{cache.dtype}")
+    if not 0 <= position < cache.shape[0]:
+        raise ValueError(f"kv_cache_update: position {position} outside cache of {cache.shape[0]}")
+    row = new_kv.nbytes
+    call("pgk_memcpy_d2d", C.c_void_p(cache.data_ptr() + position * row), new_kv._p, row, None)
+
+
+def kv_cache_prefill(new_kv: GPUArray, cache: GPUArray, start_pos: int = 0) -> None:
+    """new_kv [S, Hkv, D] -> cache[start_pos : start_pos + S] of a sequence-major cache (embedding.py:103-125)."""
+    if new_kv.ndim != 3 or cache.ndim != 3 or new_kv.shape[1:] != cache.shape[1:] or new_kv.dtype != cache.dtype:
+        raise ValueError(f"kv_cache_prefill: new_kv {new_kv.shape}/{new_kv.dtype} does not fit cache {cache.shape}/{cache.dtype}")
+    if start_pos < 0 or start_pos + new_kv.shape[0] > cache.shape[0]:
+        raise ValueError(f"kv_cache_prefill: rows {start_pos}..{start_pos + new_kv.shape[0]} outside cache of {cache.shape[0]}")
+    row = new_kv.nbytes // max(new_kv.shape[0], 1)
+    call("pgk_memcpy_d2d", C.c_void_p(cache.data_ptr() + start_pos * row), new_kv._p, new_kv.nbytes, None)

@@ -99,6 +99,7 @@ def fp8_available() -> bool:
 
 
 fp8_sm90_available = fp8_sm100_available = fp8_sm120_available = fp8_fp8_sm120_available = fp8_available
+gemm_fp8_available = gemm_fp8_f32_sm90_available = gemm_fp8_f32_sm100_available = gemm_fp8_f32_sm120_available = fp8_available
 
 
 def fp8_init_lut() -> None:
@@ -107,4 +108,6 @@ def fp8_init_lut() -> None:
 
 __all__ = ["matmul_fp8", "matmul_fp8_sm90", "matmul_fp8_sm100", "matmul_fp8_sm120", "gemm_fp8_f32_sm90", "gemm_fp8_f32_sm100",
            "gemm_fp8_f32_sm120", "gemm_fp8_fp8_blockwise_nt", "quantize_fp8_rows", "quantize_fp8_blocks", "fp8_available",
-           "fp8_sm90_available", "fp8_sm100_available", "fp8_sm120_available", "fp8_fp8_sm120_available", "fp8_init_lut"]
+           "fp8_sm90_available", "fp8_sm100_available", "fp8_sm120_available", "fp8_fp8_sm120_available", "fp8_init_lut",
+           "gemm_fp8_available", "gemm_fp8_f32_sm90_available", "gemm_fp8_f32_sm100_available", "gemm_fp8_f32_sm120_available"]
+

@@ -36,6 +36,36 @@ def transpose_3d_021(input: GPUArray, *, out: GPUArray | None = None) -> GPUArra
     return o
 
 
+def transpose_3d_012(input: GPUArray, *, out: GPUArray | None = None) -> GPUArray:
+    """[d0,d1,d2] -> [d0,d2,d1] (tensor.py:256-318): the last two axes swapped per slab."""
+    if input.ndim != 3:
+        raise ValueError(f"transpose_3d_012 expects 3D input, got {input.ndim}D")
+    d0, d1, d2 = input.shape
+    o = check_out(out, (d0, d2, d1), input.dtype, "transpose_3d_012")
+    call("pgk_transpose_batched", input._p, o._p, d0, d1, d2, input.itemsize, None)
+    return o
+
+
+def transpose_4d_0132(input: GPUArray, *, out: GPUArray | None = None) -> GPUArray:
+    """[d0,d1,d2,d3] -> [d0,d1,d3,d2] (tensor.py:320-380): K^T per (batch, head)."""
+    if input.ndim != 4:
+        raise ValueError(f"transpose_4d_0132 expects 4D input, got {input.ndim}D")
+    d0, d1, d2, d3 = input.shape
+    o = check_out(out, (d0, d1, d3, d2), input.dtype, "transpose_4d_0132")
+    call("pgk_transpose_batched", input._p, o._p, d0 * d1, d2, d3, input.itemsize, None)
+    return o
+
+
+def transpose_4d_0213(input: GPUArray, *, out: GPUArray | None = None) -> GPUArray:
+    """[d0,d1,d2,d3] -> [d0,d2,d1,d3] (tensor.py:191-254): [batch, seq, heads, dim] <-> [batch, heads, seq, dim]."""
+    if input.ndim != 4:
+        raise ValueError(f"transpose_4d_0213 expects 4D input, got {input.ndim}D")
+    d0, d1, d2, d3 = input.shape
+    o = check_out(out, (d0, d2, d1, d3), input.dtype, "transpose_4d_0213")
+    call("pgk_transpose_4d_0213", input._p, o._p, d0, d1, d2, d3, input.itemsize, None)
+    return o
+
+
 def reshape_copy(input: GPUArray, new_shape=None, *, out: GPUArray | None = None) -> GPUArray:
     """Copy into a new shape (tensor.py:395-477); `out` fixes the shape when given."""
     if out is None:

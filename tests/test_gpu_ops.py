@@ -786,6 +786,35 @@ def test_continuous_batching_helpers():
     assert fin.to_numpy()[1] == 1 and fin.to_numpy().sum() >= 1
 
 
+@pytest.mark.parametrize("dt", ["float32", "bfloat16"])
+def test_transposes_4d_3d_and_sequence_major_kv_cache(dt):
+    """transpose_3d_012 / 4d_0132 / 4d_0213 (tensor.py:191-380) and the un-expanded, sequence-major cache writers
+    kv_cache_update / kv_cache_prefill (embedding.py:78-125): pure data movement, exact against NumPy."""
+    rng = np.random.default_rng(61)
+    x3 = rng.standard_normal((3, 70, 45)).astype(np.float32)
+    x4 = rng.standard_normal((2, 5, 66, 24)).astype(np.float32)
+    np.testing.assert_array_equal(host(ops.transpose_3d_012(dev(x3, dt))), rounded(x3, dt).transpose(0, 2, 1))
+    np.testing.assert_array_equal(host(ops.transpose_4d_0132(dev(x4, dt))), rounded(x4, dt).transpose(0, 1, 3, 2))
+    np.testing.assert_array_equal(host(ops.transpose_4d_0213(dev(x4, dt))), rounded(x4, dt).transpose(0, 2, 1, 3))
+    out = pk.empty((2, 66, 5, 24), dt)
+    assert ops.transpose_4d_0213(dev(x4, dt), out=out) is out
+    np.testing.assert_array_equal(host(out), rounded(x4, dt).transpose(0, 2, 1, 3))
+    with pytest.raises(ValueError):
+        ops.transpose_4d_0213(dev(x3, dt))
+    cache = pk.zeros((16, 4, 32), dt)
+    new = rng.standard_normal((6, 4, 32)).astype(np.float32)
+    one = rng.standard_normal((1, 4, 32)).astype(np.float32)
+    ops.kv_cache_prefill(dev(new, dt), cache, 3)
+    ops.kv_cache_update(dev(one, dt), cache, 9)
+    want = np.zeros((16, 4, 32), np.float32)
+    want[3:9], want[9] = rounded(new, dt), rounded(one, dt)[0]
+    np.testing.assert_array_equal(host(cache), want)
+    with pytest.raises(ValueError):
+        ops.kv_cache_update(dev(one, dt), cache, 16)
+    with pytest.raises(ValueError):
+        ops.kv_cache_prefill(dev(new, dt), cache, 11)
+
+
 # ----------------------------------------------------------------------------- device sampling
 def _safe_us(lg, T, k, p, rng, n=6):
     """u values whose decision is at least 1e-4 of the kept mass away from a boundary (expf vs np.exp differ by ulps)."""

@@ -156,3 +156,70 @@ class TransformerConfig:
     @property
     def num_kv_groups(self) -> int:
         return self.num_heads // self.num_kv_heads
+
+
+# ---- legacy per-family configs (config.py:515-620): HF-style field names, converted to TransformerConfig ----------
+@dataclass
+class GPT2Config:
+    vocab_size: int = 50257
+    n_embd: int = 768
+    n_layer: int = 12
+    n_head: int = 12
+    n_positions: int = 1024
+    layer_norm_eps: float = 1e-5
+
+    @property
+    def n_inner(self) -> int:
+        return 4 * self.n_embd
+
+    def to_transformer_config(self) -> TransformerConfig:
+        return TransformerConfig(vocab_size=self.vocab_size, hidden_size=self.n_embd, num_layers=self.n_layer, num_heads=self.n_head,
+                                 num_kv_heads=self.n_head, intermediate_size=self.n_inner, norm_type="layernorm", activation="gelu",
+                                 use_rope=False, causal=True, max_position_embeddings=self.n_positions, norm_eps=self.layer_norm_eps)
+
+
+@dataclass
+class LlamaConfig:
+    vocab_size: int = 32000
+    hidden_size: int = 2048
+    intermediate_size: int = 5632
+    num_hidden_layers: int = 22
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 4
+    max_position_embeddings: int = 2048
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+    def to_transformer_config(self) -> TransformerConfig:
+        return TransformerConfig(vocab_size=self.vocab_size, hidden_size=self.hidden_size, num_layers=self.num_hidden_layers,
+                                 num_heads=self.num_attention_heads, num_kv_heads=self.num_key_value_heads,
+                                 intermediate_size=self.intermediate_size, norm_type="rmsnorm", activation="silu", use_rope=True,
+                                 causal=True, max_position_embeddings=self.max_position_embeddings, norm_eps=self.rms_norm_eps,
+                                 rope_theta=self.rope_theta)
+
+
+@dataclass
+class Qwen3Config:
+    vocab_size: int = 151936
+    hidden_size: int = 4096
+    intermediate_size: int = 12288
+    num_hidden_layers: int = 36
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    head_dim: int = 128            # not hidden_size // heads: Qwen3-0.6B is 1024 / 16 heads with 128
+    max_position_embeddings: int = 40960
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1000000.0
+
+    def to_transformer_config(self) -> TransformerConfig:
+        """The reference's conversion drops head_dim (config.py:600-616) and so gets 64 for Qwen3-0.6B; it is carried
+        through here."""
+        return TransformerConfig(vocab_size=self.vocab_size, hidden_size=self.hidden_size, num_layers=self.num_hidden_layers,
+                                 num_heads=self.num_attention_heads, num_kv_heads=self.num_key_value_heads,
+                                 intermediate_size=self.intermediate_size, _head_dim=self.head_dim, norm_type="rmsnorm",
+                                 activation="silu", use_rope=True, causal=True, max_position_embeddings=self.max_position_embeddings,
+                                 norm_eps=self.rms_norm_eps, rope_theta=self.rope_theta)

@@ -35,6 +35,15 @@ class DecodeBatch(DecodeStrategy):
         out = buffers.logits_batch.slice_rows(len(token_ids)) if buffers is not None and buffers.logits_batch is not None else None
         return matmul_nt(hidden, head, out=out)
 
+    def step_graph(self, token_ids: list[int], start_position: int, context_len: int):
+        """batch.py:308-363: the verify step for exactly `batch_size` tokens after init_graph() -> logits
+        [batch_size, vocab].  Same result as step_batch; nothing is replayed from baked scalars (the reference's
+        captured graph freezes the KV-write position): positions are read from device memory."""
+        assert self._graph_ready, "Call init_graph() first"
+        if len(token_ids) != self.batch_size:
+            raise ValueError(f"token_ids length ({len(token_ids)}) must match batch_size ({self.batch_size})")
+        return self.step_batch(token_ids, start_position, context_len, None)
+
     # ---- independent sequences on the native engine ----
     def init_graph(self, max_seq_len: int = 512) -> None:
         self._engine = self.model.build_engine(max_seq_len=max_seq_len, max_batch=self.batch_size)

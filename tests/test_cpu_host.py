@@ -157,3 +157,32 @@ def test_bench_accounting_formulas():
     assert ab["kv_read"] == 114_688 * 128 and ab["kv_write"] == 114_688
     assert bench.prefill_flops(O.QWEN3_0_6B, 128, all_rows=True) == pytest.approx(152.6e9 + 1.88e9, rel=5e-3)
     assert bench.prefill_flops(O.QWEN3_0_6B, 128, all_rows=False) == pytest.approx(113.1e9 + 1.88e9, rel=5e-3)
+
+
+def test_legacy_configs_aliases_and_numpy_rope():
+    """GPT2Config / LlamaConfig / Qwen3Config -> TransformerConfig (config.py:515-620), the legacy component names
+    (models/causal.py:1496-1501) and the host RoPE helper (layers/rope.py:27-43) against the oracle's rope."""
+    import numpy as np
+
+    from oracle import cpu_ref as O
+    from pygpukit_amd import llm
+
+    g = llm.GPT2Config().to_transformer_config()
+    assert (g.hidden_size, g.num_layers, g.num_heads, g.num_kv_heads, g.intermediate_size) == (768, 12, 12, 12, 3072)
+    assert (g.norm_type, g.activation, g.use_rope, g.max_position_embeddings) == ("layernorm", "gelu", False, 1024)
+    l = llm.LlamaConfig(hidden_size=4096, num_attention_heads=32, num_key_value_heads=8, intermediate_size=14336,
+                        num_hidden_layers=32, rope_theta=5e5).to_transformer_config()
+    assert (l.head_dim, l.num_kv_groups, l.norm_type, l.activation, l.rope_theta) == (128, 4, "rmsnorm", "silu", 5e5)
+    q = llm.Qwen3Config(hidden_size=1024, num_attention_heads=16, num_key_value_heads=8, intermediate_size=3072,
+                        num_hidden_layers=28).to_transformer_config()
+    assert (q.head_dim, q.norm_eps, q.rope_theta, q.vocab_size) == (128, 1e-6, 1e6, 151936)
+    assert llm.RMSNorm is llm.Norm and llm.LayerNorm is llm.Norm and llm.LlamaAttention is llm.Attention
+    assert llm.CausalSelfAttention is llm.Attention and llm.LlamaMLP is llm.MLP and llm.LlamaBlock is llm.TransformerBlock
+    rng = np.random.default_rng(8)
+    qh, kh = rng.standard_normal((5, 4, 64)).astype(np.float32), rng.standard_normal((5, 2, 64)).astype(np.float32)
+    cos, sin = llm.precompute_freqs_cis(64, 32, 1e6)
+    pos = [3, 4, 9, 20, 31]
+    qe, ke = llm.apply_rotary_pos_emb_numpy(qh, kh, cos[pos], sin[pos])
+    qo, ko = O.rope(qh, kh, cos[pos].astype(np.float32), sin[pos].astype(np.float32))
+    np.testing.assert_allclose(qe, qo, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ke, ko, rtol=1e-6, atol=1e-6)

@@ -10,6 +10,7 @@ pooled allocator of libpgk_hip.so; bf16 travels as uint16 on the host (core/dtyp
 from __future__ import annotations
 
 import ctypes as C
+import time
 from typing import Any
 
 import numpy as np
@@ -28,13 +29,18 @@ def _prod(shape) -> int:
 
 
 class GPUArray:
-    __slots__ = ("_shape", "_dtype", "_ptr", "_owns_memory", "_source_ref", "__weakref__")
+    __slots__ = ("_shape", "_dtype", "_ptr", "_owns_memory", "_source_ref", "_last_access", "__weakref__")
 
     def __init__(self, shape: tuple[int, ...], dtype: DataType, device_ptr: Any = None,
-                 owns_memory: bool = True, _source_ref: "GPUArray | None" = None) -> None:
+                 owns_memory: bool = True, _native: Any = None, _source_ref: "GPUArray | None" = None) -> None:
+        # `_native` keeps the reference's positional signature (array.py:33); there is no second, native array object
+        # here - an array given as `_native` is adopted as a view of its storage
+        if _native is not None and device_ptr is None:
+            device_ptr, owns_memory, _source_ref = _native.data_ptr(), False, _native
         self._shape = tuple(int(d) for d in shape)
         self._dtype = dtype
         self._source_ref = _source_ref
+        self._last_access = time.time()
         if device_ptr is None:
             _hip.require_device()
             p = C.c_void_p()
@@ -46,6 +52,11 @@ class GPUArray:
             self._owns_memory = owns_memory
 
     # ------------------------------------------------------------------ properties
+    @property
+    def last_access(self) -> float:
+        """Timestamp of the last host-visible access (array.py:174-177): construction, device_ptr, to_numpy."""
+        return self._last_access
+
     @property
     def shape(self) -> tuple[int, ...]:
         return self._shape
@@ -76,6 +87,7 @@ class GPUArray:
 
     @property
     def device_ptr(self) -> int:
+        self._last_access = time.time()
         return self._ptr
 
     @property
@@ -96,6 +108,7 @@ class GPUArray:
 
     # ------------------------------------------------------------------ host <-> device
     def to_numpy(self) -> np.ndarray:
+        self._last_access = time.time()
         out = np.empty(self._shape, dtype=self._dtype.to_numpy_dtype())
         if self.nbytes:
             _hip.call("pgk_memcpy_d2h", out.ctypes.data_as(C.c_void_p), self._p, self.nbytes, None)

@@ -35,8 +35,8 @@ def _gfx_capability(arch: str) -> tuple[int, int] | None:
 
 def get_device_info(device_id: int = 0) -> DeviceInfo:
     p = get_backend().get_device_properties(device_id)
-    return DeviceInfo(name=p["name"], total_memory=p["total_memory"], compute_capability=_gfx_capability(p["arch"]),
-                      multiprocessor_count=p["multiprocessor_count"], max_threads_per_block=1024, warp_size=p["wavefront_size"])
+    return DeviceInfo(name=p.name, total_memory=p.total_memory, compute_capability=p.compute_capability or _gfx_capability(p.arch),
+                      multiprocessor_count=p.multiprocessor_count, max_threads_per_block=p.max_threads_per_block, warp_size=p.warp_size)
 
 
 @dataclass
@@ -59,8 +59,8 @@ DeviceCapabilities = FallbackDeviceCapabilities
 
 def get_device_capabilities(device_id: int = 0) -> FallbackDeviceCapabilities:
     p = get_backend().get_device_properties(device_id)
-    m = re.match(r"gfx(\d+)", p["arch"] or "")
+    m = re.match(r"gfx(\d+)", p.arch or "")
     gfx = int(m.group(1)) if m else 0
     cdna = gfx >= 908 and gfx < 1000
-    return FallbackDeviceCapabilities(device_id=device_id, name=p["name"], sm_version=gfx, compute_capability=gfx, tensorcore=cdna,
+    return FallbackDeviceCapabilities(device_id=device_id, name=p.name, sm_version=gfx, compute_capability=gfx, tensorcore=cdna,
                                       tensorcore_fp16=cdna, tensorcore_bf16=gfx >= 910 and cdna, async_copy=gfx >= 942 and cdna)

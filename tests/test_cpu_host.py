@@ -186,3 +186,24 @@ def test_legacy_configs_aliases_and_numpy_rope():
     qo, ko = O.rope(qh, kh, cos[pos].astype(np.float32), sin[pos].astype(np.float32))
     np.testing.assert_allclose(qe, qo, rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(ke, ko, rtol=1e-6, atol=1e-6)
+
+
+def test_backend_surface_without_a_cpu_fallback():
+    """core.backend keeps the reference's names (backend.py:198-560): Backend ABC, DeviceProperties, NativeBackend,
+    get/set/reset_backend, has_rust_module - and a CPUSimulationBackend that refuses to exist."""
+    from pygpukit_amd.core import backend as B
+
+    assert issubclass(B.HipBackend, B.Backend) and B.NativeBackend is B.HipBackend
+    b = B.get_backend()
+    assert isinstance(b, B.NativeBackend) and B.get_backend() is b
+    B.reset_backend()
+    assert B.get_backend() is not b
+    B.set_backend(b)
+    assert B.get_backend() is b
+    assert B.has_rust_module() is False and B.get_rust_module() is None
+    with pytest.raises(RuntimeError, match="no CPU simulation backend"):
+        B.CPUSimulationBackend()
+    with pytest.raises(TypeError):
+        B.Backend()                      # abstract
+    p = B.DeviceProperties(name="x", total_memory=1, arch="gfx950", warp_size=64)
+    assert p["wavefront_size"] == 64 and p["arch"] == "gfx950" and p.max_threads_per_block == 1024

@@ -99,6 +99,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--long-prefill", type=int, default=2048,
                     help="also time a prefill of this many tokens (the MFMA-bound regime); 0 = skip")
+    ap.add_argument("--no-config5", action="store_true", help="skip the Llama-3-8B-shape fp8 prefill leg of 'extras' (~25 s)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra legs (batch 8 per GPU; context 2048 in bf16 and w8a16) reported under 'extras'")
     ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (result is then INVALID)")
@@ -293,6 +294,41 @@ def main() -> None:
         extras = {"config4_per_gpu_batch8": decode_leg("bf16", 8, 128),
                   "config3_ctx2048_w8a16": decode_leg("fp8", 1, 2048),
                   "ctx2048_bf16": decode_leg("bf16", 1, 2048)}
+
+        def config5_leg(S_tok=4096, reps=3):
+            """BASELINE config 5: Llama-3-8B-shape random-init weights, fp8 e4m3 x fp8 MFMA prefill of 4096 tokens (and the
+            bf16 prefill of the same model beside it).  FLOPs: projection GEMMs + causal attention + last-row lm_head."""
+            from pygpukit_amd.llm.engine import Engine
+
+            c5 = dict(S.LLAMA3_8B)
+            w5 = S.random_engine_weights(c5, seed=args.seed, fp8=True, keep_bf16=True, threads=12)
+            H5, D5, I5, V5, L5 = c5["hidden_size"], c5["head_dim"], c5["intermediate_size"], c5["vocab_size"], c5["num_layers"]
+            per_layer = H5 * (c5["num_heads"] + 2 * c5["num_kv_heads"]) * D5 + c5["num_heads"] * D5 * H5 + 3 * H5 * I5
+            flops = 2.0 * S_tok * L5 * per_layer + 2.0 * V5 * H5 + 4.0 * S_tok * S_tok * D5 * c5["num_heads"] * L5 / 2
+            toks = [int(t) for t in np.random.default_rng(4000 + args.seed).integers(0, V5, S_tok)]
+            out = {"tokens": S_tok, "layers": L5, "flops": flops}
+            for fmt, peak in (("fp8a8", 2 * MFMA_BF16_PEAK_TFLOPS), ("bf16", MFMA_BF16_PEAK_TFLOPS)):
+                e5 = Engine(c5, w5["embed"], w5["bf16"] if fmt == "bf16" else w5["fp8"], w5["final_norm"], None, max_seq_len=S_tok + 8,
+                            max_batch=1, weight_format=fmt, use_qk_norm=False)
+                e5.prefill(toks, want_last_logits=False)
+                e5.synchronize()
+                ms = []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    e5.prefill(toks, want_last_logits=False)
+                    e5.synchronize()
+                    ms.append((time.perf_counter() - t0) * 1e3)
+                best = min(ms)
+                out[fmt] = {"ms": best, "tflops": flops / best / 1e9, "frac_mfma_peak": flops / best / 1e9 / peak,
+                            "peak_tflops": peak, "runs_ms": [round(x, 2) for x in ms]}
+                del e5
+            return out
+
+        if not args.no_config5:
+            try:
+                extras["config5_llama8b_prefill4096"] = config5_leg()
+            except Exception as e:  # noqa: BLE001 - an extra leg must never take the headline down
+                extras["config5_llama8b_prefill4096"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- per-kernel timing (eager, event after every kernel) for the roofline objects ----
     prof = eng.profile_step(B, 8)

@@ -39,6 +39,9 @@ _RED = {"sum": 0, "mean": 1, "max": 2, "min": 3}
 def _reduce(a: GPUArray, name: str) -> GPUArray:
     validate_float(a, name)
     if a.size == 0:
+        if name == "sum":               # np.sum of nothing is 0 (the reference's CPU branch); max / min / mean have no value
+            from pygpukit_amd.core.factory import zeros
+            return zeros((1,), a.dtype)
         raise ValueError(f"{name} of an empty array")
     o = GPUArray((1,), a.dtype)
     call("pgk_reduce", a._p, o._p, a.size, _RED[name], a.dtype.code, None)

@@ -359,7 +359,10 @@ __global__ void embed_kernel(const bf16* embed, const int32_t* tokens, float* h,
 }
 
 // token[b] = argmax over workgroup partials (ties -> lowest index); position[b] += 1; log the token;
-// h[b] = E[token] for the next step; the last workgroup of the step bumps the step counter.
+// h[b] = E[token] for the next step; the last workgroup of the step's last chunk bumps the step counter.
+// One workgroup per sequence (grid = M).  Every workgroup reads the step counter before it takes an arrival ticket
+// (step_counter[1]); the bump is made by whoever draws the last ticket, so it cannot overtake a read.  (One workgroup
+// for the whole chunk, a wave per sequence, took 25 us at M = 8 and 57 us at M = 16 - a dependent walk per sequence.)
 __global__ __launch_bounds__(256) void finalize_kernel(const float* amax_val, const int* amax_idx, int nblk,
                                                        int32_t* tokens, int32_t* positions, int32_t* token_log,
                                                        int32_t* step_counter, int log_width, int log_cap,
@@ -367,82 +370,75 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* amax_val, co
                                                        unsigned long long* clk_log, const float* rope_cos,
                                                        const float* rope_sin, float* cur_cos, float* cur_sin, int half,
                                                        int max_seq, int M, const int32_t* sampled) {
-    // ONE workgroup for the whole chunk (the step counter is read and bumped here: with a workgroup per sequence the
-    // bump of the last one could overtake another one's read).  Wave w owns sequences w, w+4, ...
-    __shared__ int s_tok[16], s_pos[16];
     __shared__ float sv[4];
     __shared__ int si[4];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __shared__ int s_tok, s_pos;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, b = blockIdx.x;
     const int step = step_counter[0];
-    // one sequence (the latency-critical case): all four waves scan its partials; otherwise a wave per sequence
-    const int span = (M == 1) ? 256 : 64, first = (M == 1) ? (int)threadIdx.x : lane;
-    for (int b = (M == 1) ? 0 : wid; b < M; b += 4) {
-        int bi;
-        if (sampled) {
-            bi = sampled[b];                                  // temperature / top-k / top-p draw (ops_sampling.hip)
-        } else {
-            float bv = -INFINITY;
-            bi = 0x7FFFFFFF;
-            for (int i = first; i < nblk; i += span) {
-                const float v = amax_val[(size_t)b * nblk + i];
-                const int ix = amax_idx[(size_t)b * nblk + i];
-                if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float ov = __shfl_xor(bv, off, 64);
-                const int oi = __shfl_xor(bi, off, 64);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            if (M == 1) {                                       // combine the four waves
-                if (lane == 0) { sv[wid] = bv; si[wid] = bi; }
-                __syncthreads();
-                bv = sv[0]; bi = si[0];
-#pragma unroll
-                for (int w = 1; w < 4; ++w)
-                    if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
-            }
-            if (bi == 0x7FFFFFFF) bi = 0;
+    int bi;
+    if (sampled) {
+        bi = sampled[b];                                  // temperature / top-k / top-p draw (ops_sampling.hip)
+    } else {
+        float bv = -INFINITY;
+        bi = 0x7FFFFFFF;
+        for (int i = threadIdx.x; i < nblk; i += 256) {
+            const float v = amax_val[(size_t)b * nblk + i];
+            const int ix = amax_idx[(size_t)b * nblk + i];
+            if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
         }
-        if (lane == 0 && (M > 1 || wid == 0)) {
-            s_tok[b] = bi;
-            tokens[b] = bi;
-            const int npos = positions[b] + 1;
-            positions[b] = npos;
-            s_pos[b] = min(npos, max_seq - 1);
-            if (step < log_cap) token_log[(size_t)step * log_width + b] = bi;
-            if (b == 0 && step < log_cap && clk_log) {  // shader-clock / 100 MHz wall-clock stamps (diagnostic only)
-                clk_log[2 * (size_t)step] = __builtin_amdgcn_s_memtime();
-                clk_log[2 * (size_t)step + 1] = __builtin_amdgcn_s_memrealtime();
-            }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { sv[wid] = bv; si[wid] = bi; }
+        __syncthreads();
+        bv = sv[0]; bi = si[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        if (bi == 0x7FFFFFFF) bi = 0;
+    }
+    if (threadIdx.x == 0) {
+        s_tok = bi;
+        tokens[b] = bi;
+        const int npos = positions[b] + 1;
+        positions[b] = npos;
+        s_pos = min(npos, max_seq - 1);
+        if (step < log_cap) token_log[(size_t)step * log_width + b] = bi;
+        if (b == 0 && step < log_cap && clk_log) {  // shader-clock / 100 MHz wall-clock stamps (diagnostic only)
+            clk_log[2 * (size_t)step] = __builtin_amdgcn_s_memtime();
+            clk_log[2 * (size_t)step + 1] = __builtin_amdgcn_s_memrealtime();
         }
     }
     __syncthreads();
-    // next step's inputs for all M sequences in one flat sweep (a loop per sequence paid one memory round trip each:
-    // 24.7 us at M = 8): embedding rows, 8 bf16 per lane, then the RoPE rows of the next positions
+    // next step's inputs of this sequence: its embedding row (8 bf16 per lane) and the RoPE row of its next position
+    const bf16* erow = embed + (size_t)s_tok * H;
+    float* hrow = h + (size_t)b * H;
     if ((H & 7) == 0) {
-        const int vpr = H >> 3;
-        for (int idx = threadIdx.x; idx < M * vpr; idx += 256) {
-            const int b = idx / vpr, v = idx - b * vpr;
-            const uint4 raw = *reinterpret_cast<const uint4*>(embed + (size_t)s_tok[b] * H + v * 8);
+        for (int v = threadIdx.x; v < (H >> 3); v += 256) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(erow + v * 8);
             float f[8];
             WTraits<bf16>::decode(raw, f);
-            float* dst = h + (size_t)b * H + v * 8;
-            *reinterpret_cast<float4*>(dst) = make_float4(f[0], f[1], f[2], f[3]);
-            *reinterpret_cast<float4*>(dst + 4) = make_float4(f[4], f[5], f[6], f[7]);
+            *reinterpret_cast<float4*>(hrow + v * 8) = make_float4(f[0], f[1], f[2], f[3]);
+            *reinterpret_cast<float4*>(hrow + v * 8 + 4) = make_float4(f[4], f[5], f[6], f[7]);
         }
     } else {
-        for (int idx = threadIdx.x; idx < M * H; idx += 256) {
-            const int b = idx / H;
-            h[idx] = to_f(embed[(size_t)s_tok[b] * H + (idx - b * H)]);
+        for (int i = threadIdx.x; i < H; i += 256) hrow[i] = to_f(erow[i]);
+    }
+    for (int i = threadIdx.x; i < half; i += 256) {
+        cur_cos[(size_t)b * half + i] = rope_cos[(size_t)s_pos * half + i];
+        cur_sin[(size_t)b * half + i] = rope_sin[(size_t)s_pos * half + i];
+    }
+    if (bump && threadIdx.x == 0) {
+        if (M == 1) {
+            step_counter[0] = step + 1;
+        } else if (atomicAdd(&step_counter[1], 1) == M - 1) {   // every workgroup has read `step` before its own ticket
+            atomicExch(&step_counter[1], 0);
+            step_counter[0] = step + 1;
         }
     }
-    for (int idx = threadIdx.x; idx < M * half; idx += 256) {
-        const int b = idx / half, i = idx - b * half;
-        cur_cos[idx] = rope_cos[(size_t)s_pos[b] * half + i];
-        cur_sin[idx] = rope_sin[(size_t)s_pos[b] * half + i];
-    }
-    if (bump && threadIdx.x == 0) step_counter[0] = step + 1;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1219,7 +1215,7 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
         sampled = e->sampled + b0;
         *launches += 1;
     }
-    finalize_kernel<<<1, 256, 0, st>>>(e->amax_val + (size_t)b0 * e->lm_blocks, e->amax_idx + (size_t)b0 * e->lm_blocks,
+    finalize_kernel<<<M, 256, 0, st>>>(e->amax_val + (size_t)b0 * e->lm_blocks, e->amax_idx + (size_t)b0 * e->lm_blocks,
                                        e->lm_blocks, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
                                        e->cfg.max_batch, e->log_cap, e->embed, h, H, last ? 1 : 0, b0 == 0 ? e->clk_log : nullptr,
                                        e->rope_cos, e->rope_sin, e->cur_cos + (size_t)b0 * (D / 2), e->cur_sin + (size_t)b0 * (D / 2),
@@ -1285,7 +1281,7 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
         sampled = e->sampled + b0;
         *launches += 1;
     }
-    finalize_kernel<<<1, 256, 0, st>>>(a.amax_val, a.amax_idx, nblk, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
+    finalize_kernel<<<M, 256, 0, st>>>(a.amax_val, a.amax_idx, nblk, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
                                        e->cfg.max_batch, e->log_cap, e->embed, h, H, last ? 1 : 0, b0 == 0 ? e->clk_log : nullptr,
                                        e->rope_cos, e->rope_sin, e->cur_cos + (size_t)b0 * (D / 2), e->cur_sin + (size_t)b0 * (D / 2),
                                        D / 2, c.max_seq_len, M, sampled);

@@ -207,6 +207,185 @@ __global__ __launch_bounds__(256) void batched_mfma_kernel(FusedArgs a, int M, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Register-resident variant (K = 128 S, S in {8, 16, 24, 32}): the default.
+//
+// The LDS-image kernel above spends its time before the first MFMA: every workgroup reads all M rows twice (sum of
+// squares, then normalise), writes a K x 16 image to LDS and crosses two barriers - 9-13 us per projection at M = 16
+// where the M = 1 GEMV kernels take 4.6-5.8.  A wave only ever multiplies ITS quarter of K, so here each wave loads that
+// quarter of the activation rows straight from global memory in A-fragment shape (lane l: row l & 15, k = 32 s + 8 (l >> 4)
+// .. + 8), keeps the raw fp32 values in registers while the row sums of squares cross the waves (64 floats of LDS,
+// one barrier), and converts in place: no activation image, one pass over the rows.
+// RPG = weight rows per workgroup (16, 8 or 4): the N = hidden projections have only N / 16 = 64 row groups at
+// N = 1024, far too few workgroups to pull HBM bandwidth; with RPG < 16 the lanes of the unused B columns load nothing
+// and the epilogue ignores those columns (the MFMA computes them on whatever the registers hold - columns are
+// independent).
+template <class WT, int PRO, int EPI, int S, int RPG>
+__global__ __launch_bounds__(256) void batched_reg_kernel(FusedArgs a, int M, int nblk_logits) {
+    constexpr bool FP8 = std::is_same<WT, fp8e4m3>::value;
+    constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
+    __shared__ float s_ss[4][16];
+    __shared__ float red[NT * 4 * 256];                    // [NT][4 waves][16 m][16 n]
+    const int K = a.K, N = a.N;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, q = lane >> 4, l15 = lane & 15;
+    const int ngroups = (N + RPG - 1) / RPG;
+    const int kw0 = wid * S * 32;
+    const bool wlane = l15 < RPG;                          // this lane holds a real weight row
+    uint4 wv[NT][S];
+    float wsc[NT][S];
+    auto load_w = [&](int n0) {
+        const int nrow = min(n0 + l15, N - 1);
+        if (wlane) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const size_t row = (size_t)(t == 0 ? nrow : N + nrow);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const int k = kw0 + s * 32 + 8 * q;
+                    if constexpr (FP8) {
+                        const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(a.w) + row * K + k);
+                        wv[t][s] = make_uint4(v.x, v.y, 0, 0);
+                        wsc[t][s] = to_f(a.wscale[(row >> 7) * (size_t)(K >> 7) + (k >> 7)]);
+                    } else {
+                        wv[t][s] = load_nt16(reinterpret_cast<const bf16*>(a.w) + row * K + k);
+                    }
+                }
+            }
+        }
+    };
+    load_w(blockIdx.x * RPG);                              // in flight before the activations are touched
+    const int em = tid >> 4, en = tid & 15;
+
+    // ---- activation fragments of this wave's K quarter ----
+    const float* src = ((PRO == PRO_NORM) ? a.h : a.xin) + (size_t)min(l15, M - 1) * K + kw0 + 8 * q;
+    uint4 af[S];
+    auto pack8 = [](const float4& u, const float4& v, float inv, const float* g) {
+        return make_uint4(pack_bf16x2(u.x * inv * g[0], u.y * inv * g[1]), pack_bf16x2(u.z * inv * g[2], u.w * inv * g[3]),
+                          pack_bf16x2(v.x * inv * g[4], v.y * inv * g[5]), pack_bf16x2(v.z * inv * g[6], v.w * inv * g[7]));
+    };
+    if constexpr (PRO == PRO_NORM) {
+        constexpr bool HOLD = S <= 8;                      // raw rows stay in registers across the reduction
+        float4 r0[HOLD ? S : 1], r1[HOLD ? S : 1];
+        float ss = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float4 u = *reinterpret_cast<const float4*>(src + s * 32), v = *reinterpret_cast<const float4*>(src + s * 32 + 4);
+            if constexpr (HOLD) { r0[s] = u; r1[s] = v; }
+            ss += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w + v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        if (q == 0) s_ss[wid][l15] = ss;
+        __syncthreads();
+        const float inv = 1.0f / sqrtf((s_ss[0][l15] + s_ss[1][l15] + s_ss[2][l15] + s_ss[3][l15]) / K + a.eps);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            Vec<bf16> gr;
+            gr.load(a.gamma + kw0 + s * 32 + 8 * q);
+            float g[8];
+            gr.to_float(g);
+            if constexpr (HOLD) {
+                af[s] = pack8(r0[s], r1[s], inv, g);
+            } else {
+                const float4 u = *reinterpret_cast<const float4*>(src + s * 32), v = *reinterpret_cast<const float4*>(src + s * 32 + 4);
+                af[s] = pack8(u, v, inv, g);
+            }
+        }
+    } else {
+        const float one[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float4 u = *reinterpret_cast<const float4*>(src + s * 32), v = *reinterpret_cast<const float4*>(src + s * 32 + 4);
+            af[s] = pack8(u, v, 1.0f, one);
+        }
+    }
+    if (l15 >= M) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) af[s] = make_uint4(0, 0, 0, 0);      // rows past the batch contribute nothing
+    }
+
+    auto bfrag = [&](int t, int s) -> uint4 {
+        if constexpr (FP8) {
+            const f32x2 c0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)wv[t][s].x, false), c1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)wv[t][s].x, true);
+            const f32x2 c2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)wv[t][s].y, false), c3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)wv[t][s].y, true);
+            const float sc = wsc[t][s];
+            return make_uint4(pack_bf16x2(c0.x * sc, c0.y * sc), pack_bf16x2(c1.x * sc, c1.y * sc), pack_bf16x2(c2.x * sc, c2.y * sc),
+                              pack_bf16x2(c3.x * sc, c3.y * sc));
+        } else {
+            return wv[t][s];
+        }
+    };
+    float bv = -INFINITY;
+    int bi = 0x7FFFFFFF;
+    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int n0 = g * RPG;
+        if (g != (int)blockIdx.x) load_w(n0);
+        float resv = 0.f;
+        if constexpr (EPI == EPI_RESID) resv = a.res[(size_t)min(em, M - 1) * a.ld_out + min(n0 + en, N - 1)];
+        f32x4_b acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4_b{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b, af[s]), __builtin_bit_cast(bf16x8_b, bfrag(t, s)), acc[t], 0, 0, 0);
+        __syncthreads();                                    // the previous trip's partial tiles have been read
+        if (wlane) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[((t * 4 + wid) * 16 + q * 4 + r) * 16 + l15] = acc[t][r];
+        }
+        __syncthreads();
+        const bool ok = em < M && en < RPG && n0 + en < N;
+        float y[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float* p = red + (size_t)t * 4 * 256 + em * 16 + en;
+            y[t] = ok ? p[0] + p[256] + p[512] + p[768] : 0.f;
+        }
+        const size_t o = (size_t)em * a.ld_out + n0 + en;
+        if constexpr (EPI == EPI_STORE) {
+            if (ok) a.out[o] = y[0];
+        } else if constexpr (EPI == EPI_RESID) {
+            if (ok) a.out[o] = resv + y[0];
+        } else if constexpr (EPI == EPI_SWIGLU) {
+            if (ok) a.out[o] = y[0] / (1.0f + __expf(-y[0])) * y[NT - 1];
+        } else {   // EPI_LOGITS
+            if (ok) {
+                a.out[o] = y[0];
+                if (y[0] > bv) { bv = y[0]; bi = n0 + en; }
+            }
+        }
+    }
+    if constexpr (EPI == EPI_LOGITS) {
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (en == 0 && em < M) {
+            a.amax_val[(size_t)em * nblk_logits + blockIdx.x] = bv;
+            a.amax_idx[(size_t)em * nblk_logits + blockIdx.x] = bi;
+        }
+    }
+}
+
+template <class WT, int PRO, int EPI, int S>
+static pgk_status launch_batched_reg(const FusedArgs& a, int M, hipStream_t st, int nblk_logits) {
+    // enough workgroups to pull HBM bandwidth: fewer weight rows per workgroup when N / 16 would leave CUs idle
+    int rpg = (EPI == EPI_LOGITS || ceil_div(a.N, 16) >= 192) ? 16 : (ceil_div(a.N, 8) >= 192 ? 8 : 4);
+    if (const char* e = getenv("PGK_BATCHED_RPG")) { const int v = atoi(e); if (EPI != EPI_LOGITS && rpg != 16 && (v == 4 || v == 8 || v == 16)) rpg = v; }
+    const int grid = (EPI == EPI_LOGITS) ? nblk_logits : ceil_div(a.N, rpg);
+    if (rpg == 16) batched_reg_kernel<WT, PRO, EPI, S, 16><<<grid, 256, 0, st>>>(a, M, nblk_logits);
+    else if (rpg == 8) batched_reg_kernel<WT, PRO, EPI, S, 8><<<grid, 256, 0, st>>>(a, M, nblk_logits);
+    else batched_reg_kernel<WT, PRO, EPI, S, 4><<<grid, 256, 0, st>>>(a, M, nblk_logits);
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
+}
+
 template <class WT, int PRO, int EPI, int MP, int S>
 static pgk_status launch_batched_s(const FusedArgs& a, int M, int steps, int grid, size_t lds, hipStream_t st, int nblk_logits) {
     static bool done = false;
@@ -224,6 +403,15 @@ template <class WT, int PRO, int EPI>
 static pgk_status launch_batched(const FusedArgs& a, int M, hipStream_t st, int nblk_logits = 0) {
     PGK_REQUIRE(a.K % 128 == 0 && M >= 1 && M <= 16, "batched decode projection: K=%d must be a multiple of 128 and M=%d in [1,16]", a.K, M);
     const int steps = a.K / 128, ngroups = ceil_div(a.N, 16);
+    {   // register-resident activations (PGK_BATCHED_REG=0: the LDS-image kernel below, for A/B runs)
+        static const bool use_reg = [] { const char* e = getenv("PGK_BATCHED_REG"); return !(e && atoi(e) == 0); }();
+        if (use_reg) {
+            if (steps == 8) return launch_batched_reg<WT, PRO, EPI, 8>(a, M, st, nblk_logits);
+            if (steps == 16) return launch_batched_reg<WT, PRO, EPI, 16>(a, M, st, nblk_logits);
+            if (steps == 24) return launch_batched_reg<WT, PRO, EPI, 24>(a, M, st, nblk_logits);
+            if (steps == 32) return launch_batched_reg<WT, PRO, EPI, 32>(a, M, st, nblk_logits);
+        }
+    }
     // the prologue (RMSNorm of the M rows) is per workgroup: large N (lm_head) runs 2048 workgroups over several groups each
     const int grid = (EPI == EPI_LOGITS) ? nblk_logits : ngroups;
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;

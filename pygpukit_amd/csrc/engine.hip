@@ -978,8 +978,8 @@ struct Engine {
     const bf16 *embed, *lm_head, *final_norm;
     std::vector<pgk_layer_weights_t> layers;
     int nsplit = 1, lm_blocks = 1, lm_cap = 1, log_cap = 4096;
-    bool batched_mfma = true;   // chunks of 9..16 sequences use engine_batched.cuh (PGK_BATCHED_MFMA=0: GEMV kernels, =2: from 3 up)
-    int batched_min = 9;
+    bool batched_mfma = true;   // chunks of 3 and 5..16 sequences use engine_batched.cuh (PGK_BATCHED_MFMA=0: GEMV kernels only, =2: from 3 up, =3: from 9 up)
+    int batched_min = 5;
     int cu_count = 256, attn_waves = 0;   // attn_waves: PGK_ATTN_WAVES override of the workgroups-per-CU target (0 = by batch)
     int* merge_cnt = nullptr;      // PGK_ATTN_INKERNEL_MERGE=1: split-KV attention merges inside the launch (last arriver); default: merge kernel
     bool attn_direct_ok = false;
@@ -1297,8 +1297,11 @@ static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* la
     while (b0 < batch) {
         const int rem = batch - b0;
         pgk_status r;
-        // the MFMA projections cost the same for 9 as for 16 sequences; up to 8 the GEMV kernels are faster (measured)
-        if (rem >= e->batched_min && e->batched_mfma) { const int m = rem > 16 ? 16 : rem; r = decode_chunk_batched<WT>(e, b0, m, rem == m, st, launches); b0 += m; }
+        // the MFMA projections cost the same for 3 as for 16 sequences (~1.0-1.2 ms per step on Qwen3-0.6B); the GEMV
+        // kernels exist for M = 1, 2, 4, 8 only, so 3 / 5 / 6 / 7 sequences would take two or three weight passes there
+        // (measured: 7 sequences 2.46 ms against 1.05).  GEMV stays for exactly 1, 2 and 4 (0.70 / ~0.75 / 0.86 ms).
+        const bool mfma_ok = e->batched_mfma && (rem >= e->batched_min || (e->batched_min == 5 && rem == 3));
+        if (mfma_ok) { const int m = rem > 16 ? 16 : rem; r = decode_chunk_batched<WT>(e, b0, m, rem == m, st, launches); b0 += m; }
         else if (rem >= 8) { r = decode_chunk<WT, bf16, 8>(e, b0, rem == 8, st, launches); b0 += 8; }
         else if (rem >= 4) { r = decode_chunk<WT, bf16, 4>(e, b0, rem == 4, st, launches); b0 += 4; }
         else if (rem >= 2) { r = decode_chunk<WT, float, 2>(e, b0, rem == 2, st, launches); b0 += 2; }
@@ -1385,7 +1388,7 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
     e->lm_cap = e->lm_blocks > ceil_div(c.vocab_size, 16) ? e->lm_blocks : ceil_div(c.vocab_size, 16);   // per-sequence argmax partial slots
     {
         const char* ev = getenv("PGK_BATCHED_MFMA");
-        e->batched_min = (ev && atoi(ev) == 2) ? 3 : 9;
+        e->batched_min = (ev && atoi(ev) == 2) ? 3 : ((ev && atoi(ev) == 3) ? 9 : 5);   // 2: from 3 up; 3: the old threshold of 9
         const char* ed = getenv("PGK_ATTN_DIRECT");
         e->attn_direct_ok = c.max_seq_len <= 512 && !(ed && atoi(ed) == 0);
         e->batched_mfma = !(ev && atoi(ev) == 0) && c.hidden_size % 128 == 0 && c.intermediate_size % 128 == 0 &&

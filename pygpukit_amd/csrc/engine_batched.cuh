@@ -404,8 +404,8 @@ static pgk_status launch_batched(const FusedArgs& a, int M, hipStream_t st, int 
     PGK_REQUIRE(a.K % 128 == 0 && M >= 1 && M <= 16, "batched decode projection: K=%d must be a multiple of 128 and M=%d in [1,16]", a.K, M);
     const int steps = a.K / 128, ngroups = ceil_div(a.N, 16);
     {   // register-resident activations (PGK_BATCHED_REG=0: the LDS-image kernel below, for A/B runs)
-        static const bool use_reg = [] { const char* e = getenv("PGK_BATCHED_REG"); return !(e && atoi(e) == 0); }();
-        if (use_reg) {
+        const char* re = getenv("PGK_BATCHED_REG");
+        if (!(re && atoi(re) == 0)) {
             if (steps == 8) return launch_batched_reg<WT, PRO, EPI, 8>(a, M, st, nblk_logits);
             if (steps == 16) return launch_batched_reg<WT, PRO, EPI, 16>(a, M, st, nblk_logits);
             if (steps == 24) return launch_batched_reg<WT, PRO, EPI, 24>(a, M, st, nblk_logits);

@@ -319,7 +319,6 @@ __global__ __launch_bounds__(256) void batched_reg_kernel(FusedArgs a, int M, in
     int bi = 0x7FFFFFFF;
     for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const int n0 = g * RPG;
-        if (g != (int)blockIdx.x) load_w(n0);
         float resv = 0.f;
         if constexpr (EPI == EPI_RESID) resv = a.res[(size_t)min(em, M - 1) * a.ld_out + min(n0 + en, N - 1)];
         f32x4_b acc[NT];
@@ -330,6 +329,8 @@ __global__ __launch_bounds__(256) void batched_reg_kernel(FusedArgs a, int M, in
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b, af[s]), __builtin_bit_cast(bf16x8_b, bfrag(t, s)), acc[t], 0, 0, 0);
+        // the next group's weights (lm_head: a workgroup walks several groups) travel while this one is reduced and stored
+        if (g + (int)gridDim.x < ngroups) load_w((g + (int)gridDim.x) * RPG);
         __syncthreads();                                    // the previous trip's partial tiles have been read
         if (wlane) {
 #pragma unroll

@@ -68,7 +68,8 @@ def test_device_info_and_raw_copies():
     free, total = M.get_memory_info()
     assert 0 < free <= total == info.total_memory
     src = np.arange(4096, dtype=np.float32)
-    a, b = pk.zeros((4096,)), pk.zeros((4096,))
+    a, b, c = pk.zeros((4096,)), pk.zeros((4096,)), pk.zeros((4096,))
+    M.synchronize()          # the zero fills run on the library's stream; the copies below use another one
     M.copy_to_device(a, src.ctypes.data, src.nbytes)
     np.testing.assert_array_equal(a.to_numpy(), src)
     st = pk.Stream()
@@ -77,7 +78,6 @@ def test_device_info_and_raw_copies():
     st.synchronize()
     M.synchronize()
     np.testing.assert_array_equal(b.to_numpy(), np.concatenate([src[:2048], src[:2048]]))
-    c = pk.zeros((4096,))
     M.copy_device_to_device_async(c, a, st)
     st.synchronize()
     np.testing.assert_array_equal(c.to_numpy(), src)

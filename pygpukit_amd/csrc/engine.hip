@@ -1391,8 +1391,11 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         e->batched_min = (ev && atoi(ev) == 2) ? 3 : ((ev && atoi(ev) == 3) ? 9 : 5);   // 2: from 3 up; 3: the old threshold of 9
         const char* ed = getenv("PGK_ATTN_DIRECT");
         e->attn_direct_ok = c.max_seq_len <= 512 && !(ed && atoi(ed) == 0);
-        e->batched_mfma = !(ev && atoi(ev) == 0) && c.hidden_size % 128 == 0 && c.intermediate_size % 128 == 0 &&
-                          (c.num_heads * c.head_dim) % 128 == 0;
+        // every projection's K must suit the MFMA decode kernels: K = 128 S with S in {8, 16, 24, 32} (activation
+        // fragments in registers) or an LDS image of K x 16 bf16 that fits (K <= 4096); Llama-3-8B's down_proj
+        // (K = 14336) does neither, so such models decode batches in GEMV chunks of 8 / 4 / 2 / 1
+        auto k_ok = [](int K) { return K % 128 == 0 && K <= 4096; };
+        e->batched_mfma = !(ev && atoi(ev) == 0) && k_ok(c.hidden_size) && k_ok(c.intermediate_size) && k_ok(c.num_heads * c.head_dim);
     }
     {
         // Off by default: measured at context 2048 the release/acquire hand-off costs more than the kernel boundary it

@@ -563,11 +563,36 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     __shared__ float attn_out[DIRECT ? G * D : 1];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane % LPR;
     const int kvh = blockIdx.y, b = blockIdx.z;
+    const size_t head_off = (((size_t)b * a.hkv + kvh) * a.max_seq) * D;
+    if constexpr (DIRECT) {
+        // One workgroup owns the whole (short) context.  As in attn_oproj_kernel, the first U0 position-groups per wave
+        // are loaded from clamped addresses BEFORE the position is known, so the K/V bytes, the q/k/v row and the
+        // position share one memory round trip (the split path below learns the position first, then walks:
+        // two dependent trips - 9.2 us against 6.x for 8 sequences).
+        constexpr int U0 = 12;
+        KVBatch<U0> kb0;
+        kv_issue<D, U0, 4>(kb0, a.kcache + head_off, a.vcache + head_off, wid * PPW, a.max_seq - 1, lane);
+        const int pos = a.positions[b];
+        NewToken<D, G> t;
+        prepare_new_token<D, G>(a, b, kvh, pos, lane, t);
+        if (pos < a.max_seq && wid == 0 && lane < LPR) {
+            *reinterpret_cast<uint4*>(a.kcache + head_off + (size_t)pos * D + sub * 8) = t.kbits;
+            *reinterpret_cast<uint4*>(a.vcache + head_off + (size_t)pos * D + sub * 8) = t.vbits;
+        }
+        DecodeState<G> st;
+        st.init();
+        const int c1 = min(pos, a.max_seq);
+        kv_consume<D, G, U0, 4>(kb0, wid * PPW, c1, t.qf, lane, st);
+        if (c1 > U0 * 4 * PPW) decode_walk<bf16, D, G>(a.kcache + head_off, a.vcache + head_off, U0 * 4 * PPW, c1, t.qf, lane, wid, st);
+        if (pos < a.max_seq && wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
+        decode_block_merge_lds<D, G>(st, lds, attn_out, lane, wid);
+        for (int e = threadIdx.x; e < G * D; e += 256) a.attn_direct[((size_t)b * a.hq + (size_t)kvh * G) * D + e] = attn_out[e];
+        return;
+    }
     const int pos = a.positions[b];
     const int ctx = min(pos + 1, a.max_seq);
     NewToken<D, G> t;
     prepare_new_token<D, G>(a, b, kvh, pos, lane, t);
-    const size_t head_off = (((size_t)b * a.hkv + kvh) * a.max_seq) * D;
     const int chunk = decode_chunk_len(ctx, a.nsplit);
     const int c0 = min((int)blockIdx.x * chunk, ctx), c1 = min(c0 + chunk, ctx);
     const bool owns_new = (pos < a.max_seq) && (pos >= c0) && (pos < c1);

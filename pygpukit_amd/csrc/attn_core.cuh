@@ -167,6 +167,21 @@ __device__ __forceinline__ void kv_consume(const KVBatch<U>& kb, int p0, int c1,
     }
 }
 
+// decode_walk for bf16 caches in trips of U position-groups through kv_issue / kv_consume: all 2 U loads of a trip in
+// flight together, ONE softmax rescale per trip.  U = 8 covers 128 positions (D = 128) per trip, so a split-KV slice of
+// the usual 64-100 positions is one memory round trip (the per-position walk above made two, the second nearly empty).
+template <int D, int G, int U = 8, int NWV = 4>
+__device__ __forceinline__ void decode_walk_trips(const bf16* kbase, const bf16* vbase, int c0, int c1, const float (&qf)[G][8],
+                                                  int lane, int wid, DecodeState<G>& st) {
+    constexpr int LPR = D / 8, PPW = 64 / LPR, STRIDE = NWV * PPW;
+    for (int b0 = c0; b0 < c1; b0 += U * STRIDE) {          // workgroup-uniform trip count
+        const int p0 = b0 + wid * PPW;                      // this wave's first position of the trip
+        KVBatch<U> kb;
+        kv_issue<D, U, NWV>(kb, kbase, vbase, p0, c1 - 1, lane);
+        kv_consume<D, G, U, NWV>(kb, p0, c1, qf, lane, st);
+    }
+}
+
 // Merge the 4 waves x PPW lane-groups of a workgroup and write the chunk's partial records.
 // lds: >= 4*PPW*G*(D+2) floats.  part points at record (head g=0) for this chunk; consecutive
 // heads are `head_stride` floats apart.
@@ -254,10 +269,10 @@ __device__ __forceinline__ float decode_combine(const float* recs, int nsplit, i
 
 // Chunking rule shared by producer and consumer: nsplit fixed at capture time from max_seq,
 // chunk length derived from the live context length (read from device memory under a graph).
-__device__ __host__ __forceinline__ int decode_chunk_len(int ctx, int nsplit) {
+__device__ __host__ __forceinline__ int decode_chunk_len(int ctx, int nsplit, int gran = 32) {
     int c = (ctx + nsplit - 1) / nsplit;
-    c = (c + 31) & ~31;  // multiples of 32 positions keep every wave-instruction inside one chunk
-    return c < 32 ? 32 : c;
+    c = (c + gran - 1) / gran * gran;  // whole position-group steps (4 waves x 64 / (D/8) rows: 32 at D = 64, 16 at D = 128)
+    return c < gran ? gran : c;
 }
 
 }  // namespace pgk

@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     const int ctx = min(pos + 1, a.max_seq);
     NewToken<D, G> t;
     prepare_new_token<D, G>(a, b, kvh, pos, lane, t);
-    const int chunk = decode_chunk_len(ctx, a.nsplit);
+    const int chunk = decode_chunk_len(ctx, a.nsplit, 4 * PPW);
     const int c0 = min((int)blockIdx.x * chunk, ctx), c1 = min(c0 + chunk, ctx);
     const bool owns_new = (pos < a.max_seq) && (pos >= c0) && (pos < c1);
     if (owns_new && wid == 0 && lane < LPR) {
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     }
     DecodeState<G> st;
     st.init();
-    decode_walk<bf16, D, G>(a.kcache + head_off, a.vcache + head_off, c0, owns_new ? min(c1, pos) : c1, t.qf, lane, wid, st);
+    decode_walk_trips<D, G>(a.kcache + head_off, a.vcache + head_off, c0, owns_new ? min(c1, pos) : c1, t.qf, lane, wid, st);
     if (owns_new && wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
     if constexpr (DIRECT) {
         // this workgroup saw the whole context: normalise here and skip the merge launch

@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
         st.init();
         const int c1 = min(pos, a.max_seq);
         kv_consume<D, G, U0, 4>(kb0, wid * PPW, c1, t.qf, lane, st);
-        if (c1 > U0 * 4 * PPW) decode_walk<bf16, D, G>(a.kcache + head_off, a.vcache + head_off, U0 * 4 * PPW, c1, t.qf, lane, wid, st);
+        if (c1 > U0 * 4 * PPW) decode_walk_trips<D, G>(a.kcache + head_off, a.vcache + head_off, U0 * 4 * PPW, c1, t.qf, lane, wid, st);
         if (pos < a.max_seq && wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
         decode_block_merge_lds<D, G>(st, lds, attn_out, lane, wid);
         for (int e = threadIdx.x; e < G * D; e += 256) a.attn_direct[((size_t)b * a.hq + (size_t)kvh * G) * D + e] = attn_out[e];
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a) {
     const int c1 = min(pos, a.max_seq);
     kv_consume<D, G, U0, NWV>(kb0, wid * PPW, c1, t.qf, lane, st);
     if (c1 > U0 * NWV * PPW)
-        decode_walk<bf16, D, G, NWV>(a.kcache + head_off, a.vcache + head_off, U0 * NWV * PPW, c1, t.qf, lane, wid, st);
+        decode_walk_trips<D, G, 8, NWV>(a.kcache + head_off, a.vcache + head_off, U0 * NWV * PPW, c1, t.qf, lane, wid, st);
     if (wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
     decode_block_merge_lds<D, G, NWV>(st, lds, attn, lane, wid);
 

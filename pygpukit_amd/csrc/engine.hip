@@ -63,6 +63,10 @@ struct FusedArgs {
     int ld_out;
     float* amax_val;      // EPI_LOGITS: [M][gridDim.x]
     int* amax_idx;
+    // batched MFMA path only: bf16 hand-off between projections (the consumer rounds to bf16 anyway, so the producer
+    // does it once and every consuming workgroup reads half the bytes)
+    const bf16* xin16;    // PRO_PLAIN: [M][K] bf16, used instead of xin when set
+    bf16* out16;          // EPI_SWIGLU: [M][ld_out] bf16, written instead of out when set
 };
 
 template <class XT> __device__ __forceinline__ void store_x(XT* xs, int i, float v);
@@ -464,6 +468,7 @@ struct AttnArgs {
     const bf16* w_o;      // [H][Hq*D]
     int H, rows_per_block;
     float* opart;         // [B][Hkv][H]
+    bf16* attn_direct16;  // whole-context variant: bf16 output instead of attn_direct (batched MFMA o_proj reads it)
 };
 
 template <int D, int G>
@@ -586,7 +591,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
         if (c1 > U0 * 4 * PPW) decode_walk_trips<D, G>(a.kcache + head_off, a.vcache + head_off, U0 * 4 * PPW, c1, t.qf, lane, wid, st);
         if (pos < a.max_seq && wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
         decode_block_merge_lds<D, G>(st, lds, attn_out, lane, wid);
-        for (int e = threadIdx.x; e < G * D; e += 256) a.attn_direct[((size_t)b * a.hq + (size_t)kvh * G) * D + e] = attn_out[e];
+        if (a.attn_direct16) {
+            for (int e = threadIdx.x; e < G * D; e += 256) a.attn_direct16[((size_t)b * a.hq + (size_t)kvh * G) * D + e] = from_f<bf16>(attn_out[e]);
+        } else {
+            for (int e = threadIdx.x; e < G * D; e += 256) a.attn_direct[((size_t)b * a.hq + (size_t)kvh * G) * D + e] = attn_out[e];
+        }
         return;
     }
     const int pos = a.positions[b];
@@ -1022,6 +1031,7 @@ struct Engine {
     bf16 *kcache = nullptr, *vcache = nullptr;
     float *rope_cos = nullptr, *rope_sin = nullptr, *cur_cos = nullptr, *cur_sin = nullptr;
     int32_t *tokens = nullptr, *positions = nullptr, *token_log = nullptr, *step_counter = nullptr;
+    bf16 *act16 = nullptr, *attnv16 = nullptr;   // batched MFMA path: bf16 hand-off of SwiGLU output and attention output
     float *h = nullptr, *h2 = nullptr, *qkv = nullptr, *part = nullptr, *opart = nullptr, *attnv = nullptr, *act = nullptr, *logits = nullptr,
           *amax_val = nullptr;
     int* amax_idx = nullptr;
@@ -1101,7 +1111,7 @@ static pgk_status launch_fused_auto(const FusedArgs& a, int n_out, hipStream_t s
 }
 
 template <int D>
-static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, hipStream_t st) {
+static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, hipStream_t st, bool direct_bf16 = false) {
     const auto& c = e->cfg;
     const auto& L = e->layers[layer];
     const int G = c.num_heads / c.num_kv_heads;
@@ -1129,7 +1139,11 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
     // batches at short context: one workgroup per (sequence, kv head) walks the whole context and writes the
     // normalised output itself - Hkv * m workgroups, and the merge launch disappears
     const bool direct = !fused && e->attn_direct_ok && m >= 4;
-    if (direct) { a.nsplit = 1; a.attn_direct = e->attnv + (size_t)b0 * c.num_heads * D; }
+    if (direct) {
+        a.nsplit = 1;
+        a.attn_direct = e->attnv + (size_t)b0 * c.num_heads * D;
+        if (direct_bf16) a.attn_direct16 = e->attnv16 + (size_t)b0 * c.num_heads * D;
+    }
     const bool inmerge = !fused && !direct && e->merge_cnt != nullptr;
     if (inmerge) { a.merge_counter = e->merge_cnt + (size_t)b0 * c.num_kv_heads; a.attn_merged = e->attnv + (size_t)b0 * c.num_heads * D; }
     dim3 grid = fused ? dim3(c.hidden_size / e->oproj_rows, c.num_kv_heads, m) : dim3(a.nsplit, c.num_kv_heads, m);
@@ -1268,13 +1282,14 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
         if (pgk_status r = launch_batched<WT, PRO_NORM, EPI_STORE>(a, M, st)) return r;
         mark(KC_NORM_QKV, st);
         if (!e->skip_attn) {
-            if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, false, st)) return r; }
-            else { if (pgk_status r = launch_attn<64>(e, l, b0, M, false, st)) return r; }
+            if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, false, st, true)) return r; }
+            else { if (pgk_status r = launch_attn<64>(e, l, b0, M, false, st, true)) return r; }
         }
         mark(KC_ATTN, st);
         a = FusedArgs{};
         a.w = L.w_o; a.wscale = (const bf16*)L.s_o; a.N = H; a.K = QD;
         a.xin = e->attnv + (size_t)b0 * QD;
+        if (e->attn_direct_ok && M >= 4) a.xin16 = e->attnv16 + (size_t)b0 * QD;   // the whole-context attention kernel wrote bf16
         a.res = h; a.out = h; a.ld_out = H;
         if (pgk_status r = launch_batched<WT, PRO_PLAIN, EPI_RESID>(a, M, st)) return r;
         mark(KC_OPROJ, st);
@@ -1282,11 +1297,13 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
         a.w = L.w_gate_up; a.wscale = (const bf16*)L.s_gate_up; a.N = I; a.K = H;
         a.h = h; a.gamma = (const bf16*)L.mlp_norm; a.eps = c.norm_eps;
         a.out = e->act + (size_t)b0 * I; a.ld_out = I;
+        a.out16 = e->act16 + (size_t)b0 * I;        // SiLU(g) * u leaves as bf16: down_proj rounds it to bf16 anyway
         if (pgk_status r = launch_batched<WT, PRO_NORM, EPI_SWIGLU>(a, M, st)) return r;
         mark(KC_GATEUP, st);
         a = FusedArgs{};
         a.w = L.w_down; a.wscale = (const bf16*)L.s_down; a.N = H; a.K = I;
         a.xin = e->act + (size_t)b0 * I;
+        a.xin16 = e->act16 + (size_t)b0 * I;
         a.res = h; a.out = h; a.ld_out = H;
         if (pgk_status r = launch_batched<WT, PRO_PLAIN, EPI_RESID>(a, M, st)) return r;
         mark(KC_DOWN, st);
@@ -1407,6 +1424,8 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
     A((void**)&e->qkv, (size_t)B * e->qkv_dim() * 4, &e->ws_bytes);
     A((void**)&e->part, (size_t)B * c.num_heads * e->nsplit * (D + 2) * 4, &e->ws_bytes);
     A((void**)&e->opart, (size_t)B * c.num_kv_heads * H * 4, &e->ws_bytes);
+    A((void**)&e->act16, (size_t)B * c.intermediate_size * 2, &e->ws_bytes);
+    A((void**)&e->attnv16, (size_t)B * c.num_heads * c.head_dim * 2, &e->ws_bytes);
     A((void**)&e->attnv, (size_t)B * c.num_heads * D * 4, &e->ws_bytes);
     A((void**)&e->act, (size_t)B * c.intermediate_size * 4, &e->ws_bytes);
     A((void**)&e->logits, (size_t)B * c.vocab_size * 4, &e->ws_bytes);

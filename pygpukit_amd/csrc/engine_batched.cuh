@@ -90,6 +90,17 @@ __global__ __launch_bounds__(256) void batched_mfma_kernel(FusedArgs a, int M, i
             gr.load(a.gamma + c * 8);
             gr.to_float(g);
         }
+        if constexpr (PRO != PRO_NORM) {
+            if (a.xin16) {                                  // bf16 hand-off: copy the stored chunks into the image
+#pragma unroll
+                for (int m = 0; m < MP; ++m) {
+                    uint4 raw = *reinterpret_cast<const uint4*>(a.xin16 + (size_t)min(m, M - 1) * K + c * 8);
+                    if (m >= M) raw = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4*>(smem + ((size_t)c * MP + m) * 16) = raw;
+                }
+                continue;
+            }
+        }
         float4 v0[MP], v1[MP];
 #pragma unroll
         for (int m = 0; m < MP; ++m) {
@@ -185,7 +196,11 @@ __global__ __launch_bounds__(256) void batched_mfma_kernel(FusedArgs a, int M, i
         } else if constexpr (EPI == EPI_RESID) {
             if (ok) a.out[o] = resv + y[0];
         } else if constexpr (EPI == EPI_SWIGLU) {
-            if (ok) a.out[o] = y[0] / (1.0f + __expf(-y[0])) * y[NT - 1];
+            if (ok) {
+                const float act = y[0] / (1.0f + __expf(-y[0])) * y[NT - 1];
+                if (a.out16) a.out16[o] = from_f<bf16>(act);
+                else a.out[o] = act;
+            }
         } else {   // EPI_LOGITS
             if (ok) {
                 a.out[o] = y[0];
@@ -291,6 +306,10 @@ __global__ __launch_bounds__(256) void batched_reg_kernel(FusedArgs a, int M, in
                 af[s] = pack8(u, v, inv, g);
             }
         }
+    } else if (a.xin16) {                                  // bf16 hand-off: the fragment is the stored 16-byte chunk
+        const bf16* src16 = a.xin16 + (size_t)min(l15, M - 1) * K + kw0 + 8 * q;
+#pragma unroll
+        for (int s = 0; s < S; ++s) af[s] = *reinterpret_cast<const uint4*>(src16 + s * 32);
     } else {
         const float one[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
 #pragma unroll
@@ -352,7 +371,11 @@ __global__ __launch_bounds__(256) void batched_reg_kernel(FusedArgs a, int M, in
         } else if constexpr (EPI == EPI_RESID) {
             if (ok) a.out[o] = resv + y[0];
         } else if constexpr (EPI == EPI_SWIGLU) {
-            if (ok) a.out[o] = y[0] / (1.0f + __expf(-y[0])) * y[NT - 1];
+            if (ok) {
+                const float act = y[0] / (1.0f + __expf(-y[0])) * y[NT - 1];
+                if (a.out16) a.out16[o] = from_f<bf16>(act);
+                else a.out[o] = act;
+            }
         } else {   // EPI_LOGITS
             if (ok) {
                 a.out[o] = y[0];

@@ -1138,7 +1138,7 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
     a.opart = e->opart ? e->opart + (size_t)b0 * c.num_kv_heads * c.hidden_size : nullptr;
     // batches at short context: one workgroup per (sequence, kv head) walks the whole context and writes the
     // normalised output itself - Hkv * m workgroups, and the merge launch disappears
-    const bool direct = !fused && e->attn_direct_ok && m >= 4;
+    const bool direct = !fused && e->attn_direct_ok && m >= 3;
     if (direct) {
         a.nsplit = 1;
         a.attn_direct = e->attnv + (size_t)b0 * c.num_heads * D;
@@ -1211,7 +1211,7 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
             a.res = h; a.out = h; a.ld_out = H;
             if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_PLAIN, EPI_RESID>(a, H, st)) return r;
             mark(KC_OPROJ, st);
-            *launches += ((e->attn_direct_ok && M >= 4) || e->merge_cnt) ? 1 : 2;   // o_proj (+ the merge kernel unless attention normalised in place)
+            *launches += ((e->attn_direct_ok && M >= 3) || e->merge_cnt) ? 1 : 2;   // o_proj (+ the merge kernel unless attention normalised in place)
         }
         // 4. act = silu(Wg x) * (Wu x), x = rmsnorm(h [+ sum of o_proj partials])
         a = FusedArgs{};
@@ -1289,7 +1289,7 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
         a = FusedArgs{};
         a.w = L.w_o; a.wscale = (const bf16*)L.s_o; a.N = H; a.K = QD;
         a.xin = e->attnv + (size_t)b0 * QD;
-        if (e->attn_direct_ok && M >= 4) a.xin16 = e->attnv16 + (size_t)b0 * QD;   // the whole-context attention kernel wrote bf16
+        if (e->attn_direct_ok && M >= 3) a.xin16 = e->attnv16 + (size_t)b0 * QD;   // the whole-context attention kernel wrote bf16
         a.res = h; a.out = h; a.ld_out = H;
         if (pgk_status r = launch_batched<WT, PRO_PLAIN, EPI_RESID>(a, M, st)) return r;
         mark(KC_OPROJ, st);
@@ -1307,7 +1307,7 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
         a.res = h; a.out = h; a.ld_out = H;
         if (pgk_status r = launch_batched<WT, PRO_PLAIN, EPI_RESID>(a, M, st)) return r;
         mark(KC_DOWN, st);
-        *launches += ((e->attn_direct_ok && M >= 4) || e->merge_cnt) ? 5 : 6;
+        *launches += ((e->attn_direct_ok && M >= 3) || e->merge_cnt) ? 5 : 6;
     }
     const int nblk = ceil_div(c.vocab_size, 16) < 2048 ? ceil_div(c.vocab_size, 16) : 2048;
     FusedArgs a{};

@@ -1341,7 +1341,7 @@ static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* la
         pgk_status r;
         // the MFMA projections cost the same for 3 as for 16 sequences (~1.0-1.2 ms per step on Qwen3-0.6B); the GEMV
         // kernels exist for M = 1, 2, 4, 8 only, so 3 / 5 / 6 / 7 sequences would take two or three weight passes there
-        // (measured: 7 sequences 2.46 ms against 1.05).  GEMV stays for exactly 1, 2 and 4 (0.70 / ~0.75 / 0.86 ms).
+        // (measured: 7 sequences 2.46 ms against 1.05).  GEMV stays for exactly 1, 2 and 4 (0.70 / 0.93 / 0.82 ms).
         const bool mfma_ok = e->batched_mfma && (rem >= e->batched_min || (e->batched_min == 5 && rem == 3));
         if (mfma_ok) { const int m = rem > 16 ? 16 : rem; r = decode_chunk_batched<WT>(e, b0, m, rem == m, st, launches); b0 += m; }
         else if (rem >= 8) { r = decode_chunk<WT, bf16, 8>(e, b0, rem == 8, st, launches); b0 += 8; }

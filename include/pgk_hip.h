@@ -389,10 +389,17 @@ pgk_status pgk_engine_set_state(pgk_engine e, const int32_t* h_tokens, const int
  * state.token = argmax, state.position += 1, and the token is appended to the engine's device
  * token log.  No host interaction: any number of steps can be queued back to back. */
 pgk_status pgk_engine_decode_step(pgk_engine e, int batch, pgk_stream s);
-/* Eager steps with a hipEvent after every kernel: per-kernel-class time sums (ms) and launch counts for the
- * 8 classes embed, norm_qkv, attn, oproj, gateup, down, lmhead, argmax (in that order).  Advances the
- * decode state like n_iters ordinary steps. */
+/* Eager steps whose every launch carries its own start/stop hipEvent (hipExtLaunchKernelGGL: the dispatch's begin -> end
+ * interval, what rocprofv3 --kernel-trace reports): per-kernel-class time sums (ms) and launch counts for the 8 classes
+ * embed, norm_qkv, attn, oproj, gateup, down, lmhead, argmax (in that order).  Advances the decode state like n_iters
+ * ordinary steps.  (Measurement only: the reference's counterpart is its KernelProfiler, native/core/profiler.hpp.) */
 pgk_status pgk_engine_profile_step(pgk_engine e, int batch, int n_iters, float* h_ms_sum, int* h_count, pgk_stream s);
+/* Timeline of ONE graph-replayed step (diagnostic): every workgroup of every kernel stamps the 100 MHz s_memrealtime
+ * counter at its first and last instruction; per launch, in launch order,
+ *   h_out[6 i .. 6 i + 5] = { kernel class, workgroups, first start, last start, first end, last end }
+ * (times in 10 ns ticks from the step's first start).  `warm` replays precede the measured one; the state advances by
+ * warm + 1 steps; the engine's own captured graph is untouched. */
+pgk_status pgk_engine_timeline(pgk_engine e, int batch, int warm, uint64_t* h_out, int max_launches, int* n_launches, pgk_stream s);
 /* Capture decode_step(batch) into a hipGraph owned by the engine / replay it. */
 pgk_status pgk_engine_capture(pgk_engine e, int batch, pgk_stream s);
 pgk_status pgk_engine_replay(pgk_engine e, int n_steps, pgk_stream s);

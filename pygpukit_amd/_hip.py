@@ -103,6 +103,7 @@ _PROTOS = {
     "pgk_engine_prefill": [_V, _I, c_i32_p, _I, _I, _V, C.POINTER(_F), _V],
     "pgk_engine_set_state": [_V, c_i32_p, c_i32_p, _I, _V], "pgk_engine_decode_step": [_V, _I, _V],
     "pgk_engine_profile_step": [_V, _I, _I, C.POINTER(_F), C.POINTER(_I), _V],
+    "pgk_engine_timeline": [_V, _I, _I, C.POINTER(C.c_uint64), _I, C.POINTER(_I), _V],
     "pgk_engine_capture": [_V, _I, _V], "pgk_engine_replay": [_V, _I, _V], "pgk_engine_logits_ptr": [_V, c_void_pp],
     "pgk_engine_read_tokens": [_V, c_i32_p, _I, _I, _V], "pgk_engine_reset_log": [_V, _V],
     "pgk_engine_set_sampling": [_V, _F, _I, _F, C.POINTER(_F), _I, _V],

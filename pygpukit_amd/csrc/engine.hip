@@ -27,8 +27,7 @@
 #include <vector>
 
 #include "attn_core.cuh"
-#include "gemv_core.cuh"
-#include "pgk_internal.h"
+#include "engine_common.cuh"
 
 namespace pgk {
 
@@ -44,31 +43,6 @@ pgk_status wsgemm_nt(const bf16* a, int lda, const void* w, const bf16* wscale, 
 // --------------------------------------------------------------------------------------------
 // Fused GEMV kernel: prologue builds x[M][K] in LDS, body streams W, epilogue consumes y.
 // --------------------------------------------------------------------------------------------
-enum { PRO_NORM = 0, PRO_PLAIN = 1, PRO_ATTN = 2, PRO_NORM_SUM = 3 };
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3 };
-
-struct FusedArgs {
-    const void* w;        // [N,K] (SWIGLU: [2*N,K], gate rows then up rows)
-    const bf16* wscale;   // fp8 block scales or null
-    int N, K;
-    const float* h;       // PRO_NORM / PRO_NORM_SUM: [M][K] residual stream
-    const bf16* gamma;
-    float eps;
-    const float* xin;     // PRO_PLAIN: [M][K]
-    const float* part;    // PRO_ATTN: [M][Hq][nsplit][D+2] ; PRO_NORM_SUM: [M][n_part][K]
-    int nsplit, hq, d;    // PRO_NORM_SUM: nsplit = number of partial vectors to add
-    float* h_out;         // PRO_NORM_SUM: workgroup 0 stores h + sum(part) here ([M][K])
-    const float* res;     // EPI_RESID: out = res + y (res may alias out)
-    float* out;           // [M][ld_out]
-    int ld_out;
-    float* amax_val;      // EPI_LOGITS: [M][gridDim.x]
-    int* amax_idx;
-    // batched MFMA path only: bf16 hand-off between projections (the consumer rounds to bf16 anyway, so the producer
-    // does it once and every consuming workgroup reads half the bytes)
-    const bf16* xin16;    // PRO_PLAIN: [M][K] bf16, used instead of xin when set
-    bf16* out16;          // EPI_SWIGLU: [M][ld_out] bf16, written instead of out when set
-};
-
 template <class XT> __device__ __forceinline__ void store_x(XT* xs, int i, float v);
 template <> __device__ __forceinline__ void store_x<float>(float* xs, int i, float v) { xs[i] = v; }
 template <> __device__ __forceinline__ void store_x<bf16>(bf16* xs, int i, float v) { xs[i] = from_f<bf16>(v); }
@@ -80,7 +54,8 @@ template <> __device__ __forceinline__ void store_x<bf16>(bf16* xs, int i, float
 // hipcc: that serialised dozens of memory round trips per kernel in the first version.)  C == 0 is the
 // generic any-K path.
 template <class WT, class XT, int M, int R, int PRO, int EPI, int C>
-__global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a) {
+__global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned long long* tl) {
+    const TLStamp tls(tl);
     constexpr int NW = WTraits<WT>::NW;
     constexpr bool FP8 = std::is_same<WT, fp8e4m3>::value;
     constexpr int KC = C * 64 * NW;           // compile-time K (0 = runtime)
@@ -346,6 +321,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a) {
             a.amax_idx[(size_t)m * gridDim.x + blockIdx.x] = bi;
         }
     }
+    tls.end();
 }
 
 // h[b][:] = E[token[b]][:]   (step entry: pgk_engine_set_state; afterwards finalize_kernel keeps h current)
@@ -373,7 +349,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* amax_val, co
                                                        const bf16* embed, float* h, int H, int bump,
                                                        unsigned long long* clk_log, const float* rope_cos,
                                                        const float* rope_sin, float* cur_cos, float* cur_sin, int half,
-                                                       int max_seq, int M, const int32_t* sampled) {
+                                                       int max_seq, int M, const int32_t* sampled, unsigned long long* tl) {
+    const TLStamp tls(tl);
     __shared__ float sv[4];
     __shared__ int si[4];
     __shared__ int s_tok, s_pos;
@@ -443,6 +420,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* amax_val, co
             step_counter[0] = step + 1;
         }
     }
+    tls.end();
 }
 
 // --------------------------------------------------------------------------------------------
@@ -562,7 +540,8 @@ __device__ __forceinline__ void fold_new_token(const NewToken<D, G>& t, DecodeSt
 
 // split path: grid (nsplit, Hkv, batch)
 template <int D, int G, bool DIRECT>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned long long* tl) {
+    const TLStamp tls(tl);
     constexpr int LPR = D / 8, PPW = 64 / LPR, RS = D + 2;
     __shared__ float lds[4 * PPW * G * RS];
     __shared__ float attn_out[DIRECT ? G * D : 1];
@@ -596,6 +575,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
         } else {
             for (int e = threadIdx.x; e < G * D; e += 256) a.attn_direct[((size_t)b * a.hq + (size_t)kvh * G) * D + e] = attn_out[e];
         }
+        tls.end();
         return;
     }
     const int pos = a.positions[b];
@@ -639,7 +619,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
                 s_last = prev == a.nsplit - 1;
             }
             __syncthreads();
-            if (!s_last) return;
+            if (!s_last) { tls.end(); return; }
             if (threadIdx.x == 0) {
                 __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next layer's launch
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -677,6 +657,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
             }
         }
     }
+    tls.end();
 }
 
 // split path, step 2: merge the nsplit (<= 64) chunk records of every head into the normalised attention
@@ -684,7 +665,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
 // owns record s's (m, l): one load each, a wave max and a wave sum give the weights; then every thread sums its
 // element over the records with independent loads.
 template <int D>
-__global__ void attn_merge_kernel(const float* part, float* attn, int hq, int nsplit) {
+__global__ void attn_merge_kernel(const float* part, float* attn, int hq, int nsplit, unsigned long long* tl) {
+    const TLStamp tls(tl);
     __shared__ float w_s[64];
     __shared__ float inv_l;
     const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
@@ -712,13 +694,15 @@ __global__ void attn_merge_kernel(const float* part, float* attn, int hq, int ns
     }
     for (; s < nsplit; ++s) o = fmaf(w_s[s], recs[(size_t)s * (D + 2) + 2 + d], o);
     attn[((size_t)b * hq + h) * D + d] = o * inv_l;
+    tls.end();
 }
 
 // fused path: grid (H / rows_per_block, Hkv, batch), 256 threads.  Every workgroup of a KV head recomputes
 // that head's (short-context) attention from L2-resident K/V, then multiplies it with ITS slice of W_o
 // (rows_per_block output rows x G*D columns), whose loads were issued before anything else.
 template <int D, int G>
-__global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a, unsigned long long* tl) {
+    const TLStamp tls(tl);
     constexpr int NWV = 4;   // 8 waves measured slower: the kernel is issue-bound per SIMD, not per wave
     constexpr int LPR = D / 8, PPW = 64 / LPR, RS = D + 2;
     constexpr int GD = G * D, LPW = GD / 8;          // lanes covering one W_o row slice
@@ -777,6 +761,7 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a) {
         acc = group_sum<LPW>(acc);
         if (lr == 0) outp[row] = acc;
     }
+    tls.end();
 }
 
 // --------------------------------------------------------------------------------------------
@@ -983,29 +968,7 @@ __global__ void bf16_rows_to_f32_kernel(const bf16* in, float* out, size_t n) {
 }
 
 // --------------------------------------------------------------------------------------------
-// Optional per-kernel-class timing of an EAGER step: a hipEvent is recorded on the launch stream after
-// every kernel; class time = event[i+1] - event[i] (kernel + its launch gap).  Used by bench.py for the
-// `roofline` object; rocprofv3 --kernel-trace gives the gap-free durations (profiles/).
-enum { KC_EMBED = 0, KC_NORM_QKV, KC_ATTN, KC_OPROJ, KC_GATEUP, KC_DOWN, KC_LMHEAD, KC_ARGMAX, KC_COUNT };
-struct KernelTimer {
-    std::vector<hipEvent_t> ev;
-    std::vector<int> cls;
-    size_t used = 0;
-};
-static thread_local KernelTimer* g_timer = nullptr;
-static inline void mark(int cls, hipStream_t st) {
-    KernelTimer* t = g_timer;
-    if (!t) return;
-    if (t->used >= t->ev.size()) {
-        hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return;
-        t->ev.push_back(e);
-        t->cls.push_back(cls);
-    }
-    t->cls[t->used] = cls;
-    (void)hipEventRecord(t->ev[t->used], st);
-    ++t->used;
-}
+thread_local Probe* g_probe = nullptr;   // measurement hooks: engine_common.cuh
 
 struct Engine {
     pgk_model_config_t cfg;
@@ -1013,7 +976,7 @@ struct Engine {
     std::vector<pgk_layer_weights_t> layers;
     int nsplit = 1, lm_blocks = 1, lm_cap = 1, log_cap = 4096;
     bool batched_mfma = true;   // chunks of 3 and 5..16 sequences use engine_batched.cuh (PGK_BATCHED_MFMA=0: GEMV kernels only, =2: from 3 up, =3: from 9 up)
-    int batched_min = 5;
+    int batched_min = 5, batched_max = 64;   // PGK_BATCHED_MAX=16: chunks of at most 16 sequences (one weight pass per chunk), the A/B switch of the tiled kernels
     int cu_count = 256, attn_waves = 0;   // attn_waves: PGK_ATTN_WAVES override of the workgroups-per-CU target (0 = by batch)
     int* merge_cnt = nullptr;      // PGK_ATTN_INKERNEL_MERGE=1: split-KV attention merges inside the launch (last arriver); default: merge kernel
     bool attn_direct_ok = false;
@@ -1024,7 +987,11 @@ struct Engine {
     void* sample_scratch = nullptr;   // top-k candidate keys (ops_sampling.hip), sized for max_batch rows
     size_t sample_scratch_cap = 0;
     int32_t* sampled = nullptr;    // [max_batch]   // max_seq <= 512: batch attention in one workgroup per (sequence, kv head)
-    int skip_attn = 0;         // PGK_DEBUG_SKIP & 16: do not launch attention at all (timing ablation)
+#ifdef PGK_ABLATION
+    int skip_attn = 0;         // -DPGK_ABLATION builds only: PGK_DEBUG_SKIP & 16 drops the attention launch (timing ablation, wrong tokens)
+#else
+    static constexpr int skip_attn = 0;
+#endif
     bool fused_attn = false;   // attn + o_proj in one kernel (short contexts, bf16 W_o)
     int oproj_rows = 32;       // W_o rows per workgroup on the fused path
     // device state
@@ -1032,6 +999,7 @@ struct Engine {
     float *rope_cos = nullptr, *rope_sin = nullptr, *cur_cos = nullptr, *cur_sin = nullptr;
     int32_t *tokens = nullptr, *positions = nullptr, *token_log = nullptr, *step_counter = nullptr;
     bf16 *act16 = nullptr, *attnv16 = nullptr;   // batched MFMA path: bf16 hand-off of SwiGLU output and attention output
+    bf16* x16 = nullptr;                         // 17..64 sequences: RMSNorm'ed rows in bf16 (norm_rows_bf16)
     float *h = nullptr, *h2 = nullptr, *qkv = nullptr, *part = nullptr, *opart = nullptr, *attnv = nullptr, *act = nullptr, *logits = nullptr,
           *amax_val = nullptr;
     int* amax_idx = nullptr;
@@ -1061,9 +1029,6 @@ static pgk_status dev_alloc(Engine* e, void** p, size_t bytes, size_t* acct) {
     return PGK_OK;
 }
 
-typedef __bf16 bf16x8_b __attribute__((ext_vector_type(8)));
-typedef float f32x4_b __attribute__((ext_vector_type(4)));
-#include "engine_batched.cuh"
 
 template <class WT, class XT, int M, int R, int PRO, int EPI, int C>
 static pgk_status launch_fused_c(const FusedArgs& a, int n_out, hipStream_t st, int force_grid) {
@@ -1078,8 +1043,7 @@ static pgk_status launch_fused_c(const FusedArgs& a, int n_out, hipStream_t st, 
     }
     int grid = force_grid ? force_grid : ceil_div(n_out, OUT_PER_TRIP * 4);
     if (grid > 1024) grid = 1024;
-    kfn<<<grid, 256, lds, st>>>(a);
-    PGK_CHECK_HIP(hipGetLastError());
+    PGK_CHECK_HIP(launch_k(kfn, dim3(grid), dim3(256), lds, st, a));
     return PGK_OK;
 }
 
@@ -1147,21 +1111,23 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
     const bool inmerge = !fused && !direct && e->merge_cnt != nullptr;
     if (inmerge) { a.merge_counter = e->merge_cnt + (size_t)b0 * c.num_kv_heads; a.attn_merged = e->attnv + (size_t)b0 * c.num_heads * D; }
     dim3 grid = fused ? dim3(c.hidden_size / e->oproj_rows, c.num_kv_heads, m) : dim3(a.nsplit, c.num_kv_heads, m);
+    hipError_t he = hipSuccess;
 #define PGK_ATTN(GG)                                                               \
     case GG:                                                                       \
-        if (fused) attn_oproj_kernel<D, GG><<<grid, 256, 0, st>>>(a);              \
-        else if (direct) attn_decode_kernel<D, GG, true><<<grid, 256, 0, st>>>(a); \
-        else attn_decode_kernel<D, GG, false><<<grid, 256, 0, st>>>(a);            \
+        if (fused) he = launch_k(attn_oproj_kernel<D, GG>, grid, dim3(256), 0, st, a);              \
+        else if (direct) he = launch_k(attn_decode_kernel<D, GG, true>, grid, dim3(256), 0, st, a); \
+        else he = launch_k(attn_decode_kernel<D, GG, false>, grid, dim3(256), 0, st, a);            \
         break;
     switch (G) {
         PGK_ATTN(1) PGK_ATTN(2) PGK_ATTN(4)
         default: return set_error(PGK_ERR_UNSUPPORTED, "engine: GQA group %d not in {1,2,4}", G);
     }
 #undef PGK_ATTN
+    PGK_CHECK_HIP(he);
     if (!fused && !direct && !inmerge) {
-        attn_merge_kernel<D><<<dim3(c.num_heads, m), D, 0, st>>>(a.part, e->attnv + (size_t)b0 * c.num_heads * D, c.num_heads, a.nsplit);
+        PGK_CHECK_HIP(launch_k(attn_merge_kernel<D>, dim3(c.num_heads, m), dim3(D), 0, st, (const float*)a.part,
+                               e->attnv + (size_t)b0 * c.num_heads * D, (int)c.num_heads, (int)a.nsplit));
     }
-    PGK_CHECK_HIP(hipGetLastError());
     return PGK_OK;
 }
 
@@ -1186,34 +1152,34 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
     // fused attention+o_proj recomputes a KV head's attention in every row-slice workgroup: right for one or
     // two sequences at short context, wasteful for a batch - batches take the split-KV path.
     const bool fused = e->fused_attn && M <= 2;
-    mark(-1, st);  // time origin
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& L = e->layers[l];
         FusedArgs a{};
         // 1. qkv = Wqkv . rmsnorm(h)
+        mark(KC_NORM_QKV);
         a.w = L.w_qkv; a.wscale = (const bf16*)L.s_qkv; a.N = NQKV; a.K = H;
         a.h = h; a.gamma = (const bf16*)L.attn_norm; a.eps = c.norm_eps;
         a.out = e->qkv + (size_t)b0 * NQKV; a.ld_out = NQKV;
         if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM, EPI_STORE>(a, NQKV, st)) return r;
-        mark(KC_NORM_QKV, st);
+        mark(KC_ATTN);
         // 2. attention (QK-norm, RoPE, KV write fused; on the fused path also the o_proj partial products)
         if (!e->skip_attn) {
             if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, fused, st)) return r; }
             else { if (pgk_status r = launch_attn<64>(e, l, b0, M, fused, st)) return r; }
         }
-        mark(KC_ATTN, st);
         const float* mlp_in = h;
         if (!fused) {
+            mark(KC_OPROJ);
             // 3. h += Wo . attn   (attn = merged split-KV records, written by attn_merge_kernel)
             a = FusedArgs{};
             a.w = L.w_o; a.wscale = (const bf16*)L.s_o; a.N = H; a.K = QD;
             a.xin = e->attnv + (size_t)b0 * QD;
             a.res = h; a.out = h; a.ld_out = H;
             if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_PLAIN, EPI_RESID>(a, H, st)) return r;
-            mark(KC_OPROJ, st);
             *launches += ((e->attn_direct_ok && M >= 3) || e->merge_cnt) ? 1 : 2;   // o_proj (+ the merge kernel unless attention normalised in place)
         }
         // 4. act = silu(Wg x) * (Wu x), x = rmsnorm(h [+ sum of o_proj partials])
+        mark(KC_GATEUP);
         a = FusedArgs{};
         a.w = L.w_gate_up; a.wscale = (const bf16*)L.s_gate_up; a.N = I; a.K = H;
         a.h = h; a.gamma = (const bf16*)L.mlp_norm; a.eps = c.norm_eps;
@@ -1230,105 +1196,123 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
         if (!done_gateup) {
             if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM, EPI_SWIGLU>(a, I, st)) return r;
         }
-        mark(KC_GATEUP, st);
         // 5. h = mlp_in + Wd . act
+        mark(KC_DOWN);
         a = FusedArgs{};
         a.w = L.w_down; a.wscale = (const bf16*)L.s_down; a.N = H; a.K = I;
         a.xin = e->act + (size_t)b0 * I;
         a.res = mlp_in; a.out = h; a.ld_out = H;
         if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_PLAIN, EPI_RESID>(a, H, st)) return r;
-        mark(KC_DOWN, st);
         *launches += 4;
     }
     // logits = E . rmsnorm(h)  (lm_head stays bf16 even when the linears are fp8)
+    mark(KC_LMHEAD);
     FusedArgs a{};
     a.w = e->lm_head; a.N = c.vocab_size; a.K = H;
     a.h = h; a.gamma = e->final_norm; a.eps = c.norm_eps;
     a.out = e->logits + (size_t)b0 * c.vocab_size; a.ld_out = c.vocab_size;
     a.amax_val = e->amax_val + (size_t)b0 * e->lm_blocks; a.amax_idx = e->amax_idx + (size_t)b0 * e->lm_blocks;
     if (pgk_status r = launch_fused<bf16, XT, M, 4, PRO_NORM, EPI_LOGITS>(a, c.vocab_size, st, e->lm_blocks)) return r;
-    mark(KC_LMHEAD, st);
+    mark(KC_ARGMAX);
     const int32_t* sampled = nullptr;
     if (e->sample_temperature > 0.f) {
         if (pgk_status r = engine_sample(e, b0, M, st)) return r;
         sampled = e->sampled + b0;
         *launches += 1;
     }
-    finalize_kernel<<<M, 256, 0, st>>>(e->amax_val + (size_t)b0 * e->lm_blocks, e->amax_idx + (size_t)b0 * e->lm_blocks,
+    PGK_CHECK_HIP(launch_k(finalize_kernel, dim3(M), dim3(256), 0, st, e->amax_val + (size_t)b0 * e->lm_blocks, e->amax_idx + (size_t)b0 * e->lm_blocks,
                                        e->lm_blocks, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
                                        e->cfg.max_batch, e->log_cap, e->embed, h, H, last ? 1 : 0, b0 == 0 ? e->clk_log : nullptr,
                                        e->rope_cos, e->rope_sin, e->cur_cos + (size_t)b0 * (D / 2), e->cur_sin + (size_t)b0 * (D / 2),
-                                       D / 2, c.max_seq_len, M, sampled);
-    PGK_CHECK_HIP(hipGetLastError());
-    mark(KC_ARGMAX, st);
+                                       D / 2, c.max_seq_len, M, sampled));
     *launches += 2;
     return PGK_OK;
 }
 
-// 3..16 sequences per chunk: every projection on the MFMA kernels of engine_batched.cuh (cost independent of M),
-// attention on the split-KV path.  Same launch sequence as decode_chunk's unfused branch: 6 L + 2.
+// 3..64 sequences per chunk: every projection on the MFMA kernels of engine_batched.hip.  Up to 16 sequences the cost of
+// a projection does not depend on M and RMSNorm is fused into the consumer's prologue (5 L + 2 launches at short
+// context); 17..64 sequences run the M-tiled kernels - each weight byte is still read ONCE per step - on rows that one
+// small launch per norm has already normalised to bf16 (7 L + 3 launches).  Attention is per sequence either way.
 template <class WT>
 static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipStream_t st, int* launches) {
     const auto& c = e->cfg;
+    constexpr bool FP8 = std::is_same<WT, fp8e4m3>::value;
     const int H = c.hidden_size, I = c.intermediate_size, D = c.head_dim, QD = c.num_heads * D, NQKV = e->qkv_dim();
     float* h = e->h + (size_t)b0 * H;
-    mark(-1, st);
+    bf16* x16 = e->x16 + (size_t)b0 * H;
+    const bool tiled = M > 16;
+    const bool direct = e->attn_direct_ok && M >= 3;
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& L = e->layers[l];
         FusedArgs a{};
+        mark(KC_NORM_QKV);
         a.w = L.w_qkv; a.wscale = (const bf16*)L.s_qkv; a.N = NQKV; a.K = H;
         a.h = h; a.gamma = (const bf16*)L.attn_norm; a.eps = c.norm_eps;
         a.out = e->qkv + (size_t)b0 * NQKV; a.ld_out = NQKV;
-        if (pgk_status r = launch_batched<WT, PRO_NORM, EPI_STORE>(a, M, st)) return r;
-        mark(KC_NORM_QKV, st);
-        if (!e->skip_attn) {
-            if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, false, st, true)) return r; }
-            else { if (pgk_status r = launch_attn<64>(e, l, b0, M, false, st, true)) return r; }
+        if (tiled) {
+            if (pgk_status r = norm_rows_bf16(h, a.gamma, x16, M, H, c.norm_eps, st)) return r;
+            a.xin16 = x16;
         }
-        mark(KC_ATTN, st);
+        if (pgk_status r = batched_proj(FP8, tiled ? PRO_PLAIN : PRO_NORM, EPI_STORE, a, M, st)) return r;
+        mark(KC_ATTN);
+        if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, false, st, true)) return r; }
+        else { if (pgk_status r = launch_attn<64>(e, l, b0, M, false, st, true)) return r; }
+        mark(KC_OPROJ);
         a = FusedArgs{};
         a.w = L.w_o; a.wscale = (const bf16*)L.s_o; a.N = H; a.K = QD;
         a.xin = e->attnv + (size_t)b0 * QD;
-        if (e->attn_direct_ok && M >= 3) a.xin16 = e->attnv16 + (size_t)b0 * QD;   // the whole-context attention kernel wrote bf16
+        if (direct) a.xin16 = e->attnv16 + (size_t)b0 * QD;   // the whole-context attention kernel wrote bf16
         a.res = h; a.out = h; a.ld_out = H;
-        if (pgk_status r = launch_batched<WT, PRO_PLAIN, EPI_RESID>(a, M, st)) return r;
-        mark(KC_OPROJ, st);
+        if (tiled && !direct) {   // long contexts: the merge kernel leaves fp32 rows; the tiled kernels read bf16 fragments
+            if (pgk_status r = norm_rows_bf16(a.xin, nullptr, e->attnv16 + (size_t)b0 * QD, M, QD, 0.f, st)) return r;
+            a.xin16 = e->attnv16 + (size_t)b0 * QD;
+            *launches += 1;
+        }
+        if (pgk_status r = batched_proj(FP8, PRO_PLAIN, EPI_RESID, a, M, st)) return r;
+        mark(KC_GATEUP);
         a = FusedArgs{};
         a.w = L.w_gate_up; a.wscale = (const bf16*)L.s_gate_up; a.N = I; a.K = H;
         a.h = h; a.gamma = (const bf16*)L.mlp_norm; a.eps = c.norm_eps;
         a.out = e->act + (size_t)b0 * I; a.ld_out = I;
         a.out16 = e->act16 + (size_t)b0 * I;        // SiLU(g) * u leaves as bf16: down_proj rounds it to bf16 anyway
-        if (pgk_status r = launch_batched<WT, PRO_NORM, EPI_SWIGLU>(a, M, st)) return r;
-        mark(KC_GATEUP, st);
+        if (tiled) {
+            if (pgk_status r = norm_rows_bf16(h, a.gamma, x16, M, H, c.norm_eps, st)) return r;
+            a.xin16 = x16;
+        }
+        if (pgk_status r = batched_proj(FP8, tiled ? PRO_PLAIN : PRO_NORM, EPI_SWIGLU, a, M, st)) return r;
+        mark(KC_DOWN);
         a = FusedArgs{};
         a.w = L.w_down; a.wscale = (const bf16*)L.s_down; a.N = H; a.K = I;
         a.xin = e->act + (size_t)b0 * I;
         a.xin16 = e->act16 + (size_t)b0 * I;
         a.res = h; a.out = h; a.ld_out = H;
-        if (pgk_status r = launch_batched<WT, PRO_PLAIN, EPI_RESID>(a, M, st)) return r;
-        mark(KC_DOWN, st);
-        *launches += ((e->attn_direct_ok && M >= 3) || e->merge_cnt) ? 5 : 6;
+        if (pgk_status r = batched_proj(FP8, PRO_PLAIN, EPI_RESID, a, M, st)) return r;
+        *launches += ((direct || e->merge_cnt) ? 5 : 6) + (tiled ? 2 : 0);
     }
     const int nblk = ceil_div(c.vocab_size, 16) < 2048 ? ceil_div(c.vocab_size, 16) : 2048;
+    mark(KC_LMHEAD);
     FusedArgs a{};
     a.w = e->lm_head; a.N = c.vocab_size; a.K = H;
     a.h = h; a.gamma = e->final_norm; a.eps = c.norm_eps;
     a.out = e->logits + (size_t)b0 * c.vocab_size; a.ld_out = c.vocab_size;
     a.amax_val = e->amax_val + (size_t)b0 * e->lm_cap; a.amax_idx = e->amax_idx + (size_t)b0 * e->lm_cap;
-    if (pgk_status r = launch_batched<bf16, PRO_NORM, EPI_LOGITS>(a, M, st, nblk)) return r;
-    mark(KC_LMHEAD, st);
+    if (tiled) {
+        if (pgk_status r = norm_rows_bf16(h, a.gamma, x16, M, H, c.norm_eps, st)) return r;
+        a.xin16 = x16;
+        *launches += 1;
+    }
+    if (pgk_status r = batched_proj(false, tiled ? PRO_PLAIN : PRO_NORM, EPI_LOGITS, a, M, st, nblk)) return r;
+    mark(KC_ARGMAX);
     const int32_t* sampled = nullptr;
     if (e->sample_temperature > 0.f) {
         if (pgk_status r = engine_sample(e, b0, M, st)) return r;
         sampled = e->sampled + b0;
         *launches += 1;
     }
-    finalize_kernel<<<M, 256, 0, st>>>(a.amax_val, a.amax_idx, nblk, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
+    PGK_CHECK_HIP(launch_k(finalize_kernel, dim3(M), dim3(256), 0, st, a.amax_val, a.amax_idx, nblk, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
                                        e->cfg.max_batch, e->log_cap, e->embed, h, H, last ? 1 : 0, b0 == 0 ? e->clk_log : nullptr,
                                        e->rope_cos, e->rope_sin, e->cur_cos + (size_t)b0 * (D / 2), e->cur_sin + (size_t)b0 * (D / 2),
-                                       D / 2, c.max_seq_len, M, sampled);
-    PGK_CHECK_HIP(hipGetLastError());
-    mark(KC_ARGMAX, st);
+                                       D / 2, c.max_seq_len, M, sampled));
     *launches += 2;
     return PGK_OK;
 }
@@ -1343,7 +1327,7 @@ static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* la
         // kernels exist for M = 1, 2, 4, 8 only, so 3 / 5 / 6 / 7 sequences would take two or three weight passes there
         // (measured: 7 sequences 2.46 ms against 1.05).  GEMV stays for exactly 1, 2 and 4 (0.70 / 0.93 / 0.82 ms).
         const bool mfma_ok = e->batched_mfma && (rem >= e->batched_min || (e->batched_min == 5 && rem == 3));
-        if (mfma_ok) { const int m = rem > 16 ? 16 : rem; r = decode_chunk_batched<WT>(e, b0, m, rem == m, st, launches); b0 += m; }
+        if (mfma_ok) { const int m = rem > e->batched_max ? e->batched_max : rem; r = decode_chunk_batched<WT>(e, b0, m, rem == m, st, launches); b0 += m; }
         else if (rem >= 8) { r = decode_chunk<WT, bf16, 8>(e, b0, rem == 8, st, launches); b0 += 8; }
         else if (rem >= 4) { r = decode_chunk<WT, bf16, 4>(e, b0, rem == 4, st, launches); b0 += 4; }
         else if (rem >= 2) { r = decode_chunk<WT, float, 2>(e, b0, rem == 2, st, launches); b0 += 2; }
@@ -1399,7 +1383,9 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         while (rows > 4 * rpp && rows % 2 == 0) rows /= 2;   // <= 4 preloaded passes per workgroup
         while (rows < rpp) rows *= 2;
         const bool tiles = rows % rpp == 0 && c.hidden_size % rows == 0 && gd / 8 <= 64;
-        if (const char* dbg = getenv("PGK_DEBUG_SKIP")) e->skip_attn = atoi(dbg) & 16;  // timing ablation only
+#ifdef PGK_ABLATION
+        if (const char* dbg = getenv("PGK_DEBUG_SKIP")) e->skip_attn = atoi(dbg) & 16;
+#endif
         const char* env = getenv("PGK_FUSED_ATTN");
         const bool want = env ? atoi(env) != 0 : true;
         e->fused_attn = want && tiles && c.weight_format == 0 && c.max_seq_len <= 512;
@@ -1426,6 +1412,7 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
     A((void**)&e->opart, (size_t)B * c.num_kv_heads * H * 4, &e->ws_bytes);
     A((void**)&e->act16, (size_t)B * c.intermediate_size * 2, &e->ws_bytes);
     A((void**)&e->attnv16, (size_t)B * c.num_heads * c.head_dim * 2, &e->ws_bytes);
+    A((void**)&e->x16, (size_t)B * H * 2, &e->ws_bytes);
     A((void**)&e->attnv, (size_t)B * c.num_heads * D * 4, &e->ws_bytes);
     A((void**)&e->act, (size_t)B * c.intermediate_size * 4, &e->ws_bytes);
     A((void**)&e->logits, (size_t)B * c.vocab_size * 4, &e->ws_bytes);
@@ -1440,6 +1427,10 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         // (K = 14336) does neither, so such models decode batches in GEMV chunks of 8 / 4 / 2 / 1
         auto k_ok = [](int K) { return K % 128 == 0 && K <= 4096; };
         e->batched_mfma = !(ev && atoi(ev) == 0) && k_ok(c.hidden_size) && k_ok(c.intermediate_size) && k_ok(c.num_heads * c.head_dim);
+        // 17..64 sequences in one weight pass (batched_mt_kernel) need K = 128 S with S instantiated; otherwise chunks of 16
+        auto k_tiled = [](int K) { const int s = K / 128; return K % 128 == 0 && (s == 2 || s == 4 || s == 8 || s == 16 || s == 24 || s == 32); };
+        e->batched_max = (k_tiled(c.hidden_size) && k_tiled(c.intermediate_size) && k_tiled(c.num_heads * c.head_dim)) ? 64 : 16;
+        if (const char* em = getenv("PGK_BATCHED_MAX")) { const int v = atoi(em); if (v >= 16 && v < e->batched_max) e->batched_max = v; }
     }
     {
         // Off by default: measured at context 2048 the release/acquire hand-off costs more than the kernel boundary it
@@ -1679,33 +1670,98 @@ pgk_status pgk_engine_profile_step(pgk_engine eh, int batch, int n_iters, float*
     PGK_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch && n_iters >= 1, "pgk_engine_profile_step: bad arguments");
     hipStream_t st = resolve_stream(s);
     for (int i = 0; i < KC_COUNT; ++i) { h_ms_sum[i] = 0.f; h_count[i] = 0; }
-    KernelTimer timer;
+    // Eager steps whose every launch carries its own start / stop event (hipExtLaunchKernelGGL): the elapsed time of a
+    // pair is the dispatch's begin -> end interval, the quantity rocprofv3 --kernel-trace reports - no launch gap, nothing
+    // subtracted.
+    Probe probe;
+    probe.timing = true;
     pgk_status r = PGK_OK;
     for (int it = 0; it < n_iters && r == PGK_OK; ++it) {
-        timer.used = 0;
-        g_timer = &timer;
-        mark(-1, st);   // calibration: two events with nothing between them measure the event's own cost,
-        mark(-2, st);   // which is subtracted from every event-to-event interval below
+        probe.used = 0;
+        probe.info.clear();
+        g_probe = &probe;
         int launches = 0;
         r = decode_step(e, batch, st, &launches);
-        g_timer = nullptr;
+        g_probe = nullptr;
         if (r != PGK_OK) break;
         hipError_t he = hipStreamSynchronize(st);
         if (he != hipSuccess) { r = set_error(PGK_ERR_HIP, "pgk_engine_profile_step: %s", hipGetErrorString(he)); break; }
-        float overhead = 0.f;
-        (void)hipEventElapsedTime(&overhead, timer.ev[0], timer.ev[1]);
-        for (size_t i = 1; i < timer.used; ++i) {
-            if (timer.cls[i] < 0) continue;  // origin / calibration markers
+        for (size_t i = 0; i < probe.used; ++i) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, timer.ev[i - 1], timer.ev[i]) == hipSuccess) {
-                ms -= overhead;
-                h_ms_sum[timer.cls[i]] += ms > 0.f ? ms : 0.f;
-                h_count[timer.cls[i]] += 1;
+            const int cls = probe.cls[i];
+            if (cls >= 0 && cls < KC_COUNT && hipEventElapsedTime(&ms, probe.ev[2 * i], probe.ev[2 * i + 1]) == hipSuccess) {
+                h_ms_sum[cls] += ms;
+                h_count[cls] += 1;
             }
         }
     }
-    for (hipEvent_t ev : timer.ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : probe.ev) (void)hipEventDestroy(ev);
     return r;
+}
+
+// Timeline of ONE replayed step (diagnostic): the step is captured into a temporary graph with every kernel's `tl` slot
+// set, replayed `warm` times and then once more; per launch the host gets
+//   h_out[6 i .. 6 i + 5] = { kernel class (KC_*), workgroups, first start, last start, first end, last end }
+// with the four times in ticks of the 100 MHz s_memrealtime counter relative to the step's first start.  The engine's
+// own captured graph is left alone; the sequence state advances by warm + 1 real steps.
+pgk_status pgk_engine_timeline(pgk_engine eh, int batch, int warm, uint64_t* h_out, int max_launches, int* n_launches, pgk_stream s) {
+    PGK_REQUIRE(eh && h_out && n_launches && max_launches >= 1 && warm >= 0, "pgk_engine_timeline: bad arguments");
+    Engine* e = (Engine*)eh;
+    PGK_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch, "pgk_engine_timeline: batch %d outside [1,%d]", batch, e->cfg.max_batch);
+    hipStream_t st = resolve_stream(s);
+    const int cap = 16 * e->cfg.num_layers + 64;
+    Probe probe;
+    probe.tl_cap = cap;
+    const size_t bytes = (size_t)cap * TL_MAXWG * 2 * sizeof(unsigned long long);
+    if (pgk_status r = pgk_malloc((void**)&probe.tl, bytes)) return r;
+    pgk_status r = PGK_OK;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ex = nullptr;
+    hipError_t he = hipMemsetAsync(probe.tl, 0, bytes, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he == hipSuccess) he = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+    if (he == hipSuccess) {
+        g_probe = &probe;
+        int launches = 0;
+        r = decode_step(e, batch, st, &launches);
+        g_probe = nullptr;
+        he = hipStreamEndCapture(st, &g);
+    }
+    if (r == PGK_OK && he == hipSuccess) he = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    for (int i = 0; r == PGK_OK && he == hipSuccess && i <= warm; ++i) he = hipGraphLaunch(ex, st);
+    if (r == PGK_OK && he == hipSuccess) he = hipStreamSynchronize(st);
+    const int n = (int)probe.info.size() < cap ? (int)probe.info.size() : cap;
+    if (r == PGK_OK && he == hipSuccess) {
+        std::vector<unsigned long long> host((size_t)n * TL_MAXWG * 2);
+        he = hipMemcpy(host.data(), probe.tl, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (he == hipSuccess) {
+            unsigned long long origin = ~0ull;
+            std::vector<unsigned long long> agg((size_t)n * 4);
+            for (int i = 0; i < n; ++i) {
+                const int nwg = probe.info[i].nwg < TL_MAXWG ? probe.info[i].nwg : TL_MAXWG;
+                unsigned long long s0 = ~0ull, s1 = 0, e0 = ~0ull, e1 = 0;
+                for (int w = 0; w < nwg; ++w) {
+                    const unsigned long long a = host[((size_t)i * TL_MAXWG + w) * 2], b = host[((size_t)i * TL_MAXWG + w) * 2 + 1];
+                    if (a == 0 && b == 0) continue;   // slot never written
+                    s0 = a < s0 ? a : s0; s1 = a > s1 ? a : s1; e0 = b < e0 ? b : e0; e1 = b > e1 ? b : e1;
+                }
+                agg[4 * i] = s0; agg[4 * i + 1] = s1; agg[4 * i + 2] = e0; agg[4 * i + 3] = e1;
+                if (s0 < origin) origin = s0;
+            }
+            *n_launches = n < max_launches ? n : max_launches;
+            for (int i = 0; i < *n_launches; ++i) {
+                h_out[6 * i] = (uint64_t)probe.info[i].cls;
+                h_out[6 * i + 1] = (uint64_t)probe.info[i].nwg;
+                for (int k = 0; k < 4; ++k) h_out[6 * i + 2 + k] = agg[4 * i] == ~0ull ? 0 : agg[4 * i + k] - origin;
+            }
+        }
+    }
+    if (ex) (void)hipGraphExecDestroy(ex);
+    if (g) (void)hipGraphDestroy(g);
+    (void)pgk_free(probe.tl);
+    if (r != PGK_OK) return r;
+    if (he != hipSuccess) return set_error(PGK_ERR_HIP, "pgk_engine_timeline: %s", hipGetErrorString(he));
+    return PGK_OK;
 }
 
 pgk_status pgk_engine_capture(pgk_engine eh, int batch, pgk_stream s) {

@@ -1,4 +1,4 @@
-// Batched decode projections on MFMA (3 <= M <= 16 sequences per launch), included by engine.hip.
+// Batched decode projections on MFMA (3 <= M <= 64 sequences per launch), included by engine_batched.hip.
 //
 // The GEMV kernels of engine.hip score every weight chunk against M activation rows with VALU dot products: 32 packed
 // dot instructions per 16-byte weight chunk at M = 8, and the kernel turns instruction-bound (gate_up 9.3 us, lm_head
@@ -16,7 +16,8 @@
 // MP: activation rows held in LDS (8 or 16).  S: 32-k steps per wave preloaded into registers (K = 128 S when it is one of
 // the instantiated 8 / 16 / 24; any further steps stream through a plain loop).
 template <class WT, int PRO, int EPI, int MP, int S>
-__global__ __launch_bounds__(256) void batched_mfma_kernel(FusedArgs a, int M, int steps /* K / 128 per wave */, int nblk_logits) {
+__global__ __launch_bounds__(256) void batched_mfma_kernel(FusedArgs a, int M, int steps /* K / 128 per wave */, int nblk_logits, unsigned long long* tl) {
+    const TLStamp tls(tl);
     constexpr bool FP8 = std::is_same<WT, fp8e4m3>::value;
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;       // weight row groups per workgroup
     constexpr int MAXS = S > 0 ? S : 1;
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256) void batched_mfma_kernel(FusedArgs a, int M, i
             a.amax_idx[(size_t)em * nblk_logits + blockIdx.x] = bi;
         }
     }
+    tls.end();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -236,7 +238,8 @@ __global__ __launch_bounds__(256) void batched_mfma_kernel(FusedArgs a, int M, i
 // and the epilogue ignores those columns (the MFMA computes them on whatever the registers hold - columns are
 // independent).
 template <class WT, int PRO, int EPI, int S, int RPG>
-__global__ __launch_bounds__(256) void batched_reg_kernel(FusedArgs a, int M, int nblk_logits) {
+__global__ __launch_bounds__(256) void batched_reg_kernel(FusedArgs a, int M, int nblk_logits, unsigned long long* tl) {
+    const TLStamp tls(tl);
     constexpr bool FP8 = std::is_same<WT, fp8e4m3>::value;
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
     __shared__ float s_ss[4][16];
@@ -395,6 +398,208 @@ __global__ __launch_bounds__(256) void batched_reg_kernel(FusedArgs a, int M, in
             a.amax_idx[(size_t)em * nblk_logits + blockIdx.x] = bi;
         }
     }
+    tls.end();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// M-tiled variant: 17..64 sequences per launch (MT = 2 or 4 tiles of 16 rows), every weight byte still read ONCE.
+//
+// Chunks of at most 16 sequences made a batch of 64 four full passes over the weights (4 x 1.08 ms per step on
+// Qwen3-0.6B).  Here a wave keeps its K quarter of the workgroup's weight rows in registers exactly as above and runs
+// MT MFMAs per weight fragment, one per 16-row tile of the batch.  The activation rows arrive as bf16 (the RMSNorm'ed
+// rows from norm_rows_bf16, the attention output, the SwiGLU output): an A fragment is one 16-byte load, no conversion,
+// no cross-wave reduction before the first MFMA.  S * MT <= 32 fragments stay resident (and are reused by every weight
+// group an lm_head workgroup walks); beyond that they stream from L2 in chunks of CH = 4 k-steps, the next chunk's loads
+// issued before the current chunk's MFMAs.  Rows >= M of the last tile repeat row M - 1: MFMA output rows are independent
+// and the epilogue drops them.
+template <class WT, int EPI, int S, int RPG, int MT>
+__global__ __launch_bounds__(256) void batched_mt_kernel(FusedArgs a, int M, int nblk_logits, unsigned long long* tl) {
+    const TLStamp tls(tl);
+    constexpr bool FP8 = std::is_same<WT, fp8e4m3>::value;
+    constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int CH = (S * MT <= 32) ? S : 4;             // k-steps per activation chunk
+    constexpr int NCH = S / CH;
+    static_assert(S % CH == 0, "chunking");
+    __shared__ float red[NT * 4 * MT * 256];               // [NT][4 waves][MT][16 m][16 n]
+    const int K = a.K, N = a.N;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, q = lane >> 4, l15 = lane & 15;
+    const int ngroups = (N + RPG - 1) / RPG;
+    const int kw0 = wid * S * 32;
+    const bool wlane = l15 < RPG;
+    uint4 wv[NT][S];
+    float wsc[NT][S];
+    auto load_w = [&](int n0) {
+        const int nrow = min(n0 + l15, N - 1);
+        if (wlane) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const size_t row = (size_t)(t == 0 ? nrow : N + nrow);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const int k = kw0 + s * 32 + 8 * q;
+                    if constexpr (FP8) {
+                        const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(a.w) + row * K + k);
+                        wv[t][s] = make_uint4(v.x, v.y, 0, 0);
+                        wsc[t][s] = to_f(a.wscale[(row >> 7) * (size_t)(K >> 7) + (k >> 7)]);
+                    } else {
+                        wv[t][s] = load_nt16(reinterpret_cast<const bf16*>(a.w) + row * K + k);
+                    }
+                }
+            }
+        }
+    };
+    load_w(blockIdx.x * RPG);                              // in flight before the activations are touched
+    const int em = tid >> 4, en = tid & 15;
+
+    const bf16* xrow[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) xrow[t] = a.xin16 + (size_t)min(t * 16 + l15, M - 1) * K + kw0 + 8 * q;
+    uint4 af[NCH > 1 ? 2 : 1][CH][MT];
+    auto load_a = [&](int buf, int c) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[buf][j][t] = *reinterpret_cast<const uint4*>(xrow[t] + (c * CH + j) * 32);
+    };
+    if constexpr (NCH == 1) load_a(0, 0);
+
+    auto bfrag = [&](int t, int s) -> uint4 {
+        if constexpr (FP8) {
+            const f32x2 c0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)wv[t][s].x, false), c1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)wv[t][s].x, true);
+            const f32x2 c2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)wv[t][s].y, false), c3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)wv[t][s].y, true);
+            const float sc = wsc[t][s];
+            return make_uint4(pack_bf16x2(c0.x * sc, c0.y * sc), pack_bf16x2(c1.x * sc, c1.y * sc), pack_bf16x2(c2.x * sc, c2.y * sc),
+                              pack_bf16x2(c3.x * sc, c3.y * sc));
+        } else {
+            return wv[t][s];
+        }
+    };
+    float bv[MT];
+    int bi[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { bv[t] = -INFINITY; bi[t] = 0x7FFFFFFF; }
+    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int n0 = g * RPG;
+        float resv[MT];
+        if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) resv[t] = a.res[(size_t)min(t * 16 + em, M - 1) * a.ld_out + min(n0 + en, N - 1)];
+        }
+        f32x4_b acc[MT][NT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[t][u] = f32x4_b{0.f, 0.f, 0.f, 0.f};
+        if constexpr (NCH > 1) load_a(0, 0);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if constexpr (NCH > 1) { if (c + 1 < NCH) load_a((c + 1) & 1, c + 1); }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    const uint4 b = bfrag(u, c * CH + j);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b, af[c & 1][j][t]),
+                                                                             __builtin_bit_cast(bf16x8_b, b), acc[t][u], 0, 0, 0);
+                }
+            }
+        }
+        // the next group's weights (lm_head: a workgroup walks several groups) travel while this one is reduced and stored
+        if (g + (int)gridDim.x < ngroups) load_w((g + (int)gridDim.x) * RPG);
+        __syncthreads();                                    // the previous trip's partial tiles have been read
+        if (wlane) {
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[(((u * 4 + wid) * MT + t) * 16 + q * 4 + r) * 16 + l15] = acc[t][u][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = t * 16 + em;
+            const bool ok = m < M && en < RPG && n0 + en < N;
+            float y[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const float* p = red + ((size_t)(u * 4) * MT + t) * 256 + em * 16 + en;
+                y[u] = ok ? p[0] + p[MT * 256] + p[2 * MT * 256] + p[3 * MT * 256] : 0.f;
+            }
+            const size_t o = (size_t)m * a.ld_out + n0 + en;
+            if constexpr (EPI == EPI_STORE) {
+                if (ok) a.out[o] = y[0];
+            } else if constexpr (EPI == EPI_RESID) {
+                if (ok) a.out[o] = resv[t] + y[0];
+            } else if constexpr (EPI == EPI_SWIGLU) {
+                if (ok) {
+                    const float act = y[0] / (1.0f + __expf(-y[0])) * y[NT - 1];
+                    if (a.out16) a.out16[o] = from_f<bf16>(act);
+                    else a.out[o] = act;
+                }
+            } else {   // EPI_LOGITS
+                if (ok) {
+                    a.out[o] = y[0];
+                    if (y[0] > bv[t]) { bv[t] = y[0]; bi[t] = n0 + en; }
+                }
+            }
+        }
+    }
+    if constexpr (EPI == EPI_LOGITS) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            float v = bv[t];
+            int ix = bi[t];
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+                const float ov = __shfl_xor(v, off, 64);
+                const int oi = __shfl_xor(ix, off, 64);
+                if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+            }
+            const int m = t * 16 + em;
+            if (en == 0 && m < M) {
+                a.amax_val[(size_t)m * nblk_logits + blockIdx.x] = v;
+                a.amax_idx[(size_t)m * nblk_logits + blockIdx.x] = ix;
+            }
+        }
+    }
+    tls.end();
+}
+
+template <class WT, int EPI, int S>
+static pgk_status launch_batched_mt(const FusedArgs& a, int M, hipStream_t st, int nblk_logits) {
+    const int rpg = (EPI == EPI_LOGITS || ceil_div(a.N, 16) >= 192) ? 16 : 4;
+    const int grid = (EPI == EPI_LOGITS) ? nblk_logits : ceil_div(a.N, rpg);
+    const bool two = M <= 32;
+    hipError_t he = hipSuccess;
+    if constexpr (EPI == EPI_LOGITS) {
+        if (two) he = launch_k(batched_mt_kernel<WT, EPI, S, 16, 2>, dim3(grid), dim3(256), 0, st, a, M, nblk_logits);
+        else he = launch_k(batched_mt_kernel<WT, EPI, S, 16, 4>, dim3(grid), dim3(256), 0, st, a, M, nblk_logits);
+    } else {
+        if (rpg == 16 && two) he = launch_k(batched_mt_kernel<WT, EPI, S, 16, 2>, dim3(grid), dim3(256), 0, st, a, M, nblk_logits);
+        else if (rpg == 16) he = launch_k(batched_mt_kernel<WT, EPI, S, 16, 4>, dim3(grid), dim3(256), 0, st, a, M, nblk_logits);
+        else if (two) he = launch_k(batched_mt_kernel<WT, EPI, S, 4, 2>, dim3(grid), dim3(256), 0, st, a, M, nblk_logits);
+        else he = launch_k(batched_mt_kernel<WT, EPI, S, 4, 4>, dim3(grid), dim3(256), 0, st, a, M, nblk_logits);
+    }
+    PGK_CHECK_HIP(he);
+    return PGK_OK;
+}
+
+template <class WT, int EPI>
+static pgk_status launch_batched_tiled(const FusedArgs& a, int M, hipStream_t st, int nblk_logits = 0) {
+    PGK_REQUIRE(a.xin16 != nullptr, "batched decode projection: %d sequences need bf16 input rows", M);
+    PGK_REQUIRE(M > 16 && M <= 64, "batched decode projection: tiled kernels take 17..64 sequences, got %d", M);
+    switch (a.K / 128) {
+        case 2: return launch_batched_mt<WT, EPI, 2>(a, M, st, nblk_logits);
+        case 4: return launch_batched_mt<WT, EPI, 4>(a, M, st, nblk_logits);
+        case 8: return launch_batched_mt<WT, EPI, 8>(a, M, st, nblk_logits);
+        case 16: return launch_batched_mt<WT, EPI, 16>(a, M, st, nblk_logits);
+        case 24: return launch_batched_mt<WT, EPI, 24>(a, M, st, nblk_logits);
+        case 32: return launch_batched_mt<WT, EPI, 32>(a, M, st, nblk_logits);
+    }
+    return set_error(PGK_ERR_UNSUPPORTED, "batched decode projection: K=%d is not 128 x {2,4,8,16,24,32}", a.K);
 }
 
 template <class WT, int PRO, int EPI, int S>
@@ -403,10 +608,11 @@ static pgk_status launch_batched_reg(const FusedArgs& a, int M, hipStream_t st, 
     int rpg = (EPI == EPI_LOGITS || ceil_div(a.N, 16) >= 192) ? 16 : (ceil_div(a.N, 8) >= 192 ? 8 : 4);
     if (const char* e = getenv("PGK_BATCHED_RPG")) { const int v = atoi(e); if (EPI != EPI_LOGITS && rpg != 16 && (v == 4 || v == 8 || v == 16)) rpg = v; }
     const int grid = (EPI == EPI_LOGITS) ? nblk_logits : ceil_div(a.N, rpg);
-    if (rpg == 16) batched_reg_kernel<WT, PRO, EPI, S, 16><<<grid, 256, 0, st>>>(a, M, nblk_logits);
-    else if (rpg == 8) batched_reg_kernel<WT, PRO, EPI, S, 8><<<grid, 256, 0, st>>>(a, M, nblk_logits);
-    else batched_reg_kernel<WT, PRO, EPI, S, 4><<<grid, 256, 0, st>>>(a, M, nblk_logits);
-    PGK_CHECK_HIP(hipGetLastError());
+    hipError_t he;
+    if (rpg == 16) he = launch_k(batched_reg_kernel<WT, PRO, EPI, S, 16>, dim3(grid), dim3(256), 0, st, a, M, nblk_logits);
+    else if (rpg == 8) he = launch_k(batched_reg_kernel<WT, PRO, EPI, S, 8>, dim3(grid), dim3(256), 0, st, a, M, nblk_logits);
+    else he = launch_k(batched_reg_kernel<WT, PRO, EPI, S, 4>, dim3(grid), dim3(256), 0, st, a, M, nblk_logits);
+    PGK_CHECK_HIP(he);
     return PGK_OK;
 }
 
@@ -418,8 +624,7 @@ static pgk_status launch_batched_s(const FusedArgs& a, int M, int steps, int gri
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         done = true;
     }
-    batched_mfma_kernel<WT, PRO, EPI, MP, S><<<grid, 256, lds, st>>>(a, M, steps, nblk_logits);
-    PGK_CHECK_HIP(hipGetLastError());
+    PGK_CHECK_HIP(launch_k(batched_mfma_kernel<WT, PRO, EPI, MP, S>, dim3(grid), dim3(256), lds, st, a, M, steps, nblk_logits));
     return PGK_OK;
 }
 

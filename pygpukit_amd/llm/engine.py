@@ -110,11 +110,27 @@ class Engine:
     KERNEL_CLASSES = ("embed", "norm_qkv", "attn", "oproj", "gateup", "down", "lmhead", "argmax")
 
     def profile_step(self, batch: int = 1, n_iters: int = 8) -> dict:
-        """Eager steps with an event after every kernel -> {class: (avg_us_per_launch, launches_per_step)}."""
+        """Eager steps, every launch bracketed by its own start/stop event (the dispatch's begin -> end interval, what
+        rocprofv3 --kernel-trace reports) -> {class: (avg_us_per_launch, launches_per_step)}."""
         ms = (C.c_float * 8)()
         cnt = (C.c_int * 8)()
         _hip.call("pgk_engine_profile_step", self.handle, batch, n_iters, ms, cnt, None)
         return {name: ((ms[i] * 1e3 / cnt[i]) if cnt[i] else 0.0, cnt[i] // n_iters) for i, name in enumerate(self.KERNEL_CLASSES)}
+
+    def timeline(self, batch: int = 1, warm: int = 2) -> list[dict]:
+        """One graph-replayed step as a list of launches in order: kernel class, workgroups, and the first/last start and
+        first/last end over the launch's workgroups in microseconds from the step's first start (in-kernel
+        s_memrealtime stamps; diagnostic capture, the engine's own graph is untouched)."""
+        cap = 16 * self.config["num_layers"] + 64
+        buf = (C.c_uint64 * (6 * cap))()
+        n = C.c_int()
+        _hip.call("pgk_engine_timeline", self.handle, batch, warm, buf, cap, C.byref(n), None)
+        out = []
+        for i in range(n.value):
+            cls, nwg, s0, s1, e0, e1 = (int(buf[6 * i + k]) for k in range(6))
+            out.append({"kernel": self.KERNEL_CLASSES[cls] if 0 <= cls < len(self.KERNEL_CLASSES) else str(cls), "workgroups": nwg,
+                        "first_start_us": s0 / 100.0, "last_start_us": s1 / 100.0, "first_end_us": e0 / 100.0, "last_end_us": e1 / 100.0})
+        return out
 
     def capture(self, batch: int = 1) -> None:
         _hip.call("pgk_engine_capture", self.handle, batch, None)

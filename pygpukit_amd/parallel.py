@@ -5,9 +5,11 @@ One process per GPU.  Independent sequences never talk to each other, so a decod
 on its data path: the global batch is partitioned by rank, each rank runs its own engine on its shard, and
 RCCL over xGMI carries only (1) the one-time broadcast of the weights from rank 0 and (2) the gather of
 the sampled tokens (4 bytes per sequence per step).  The control plane (rendezvous, barriers, timing
-reduction) is torch.distributed's gloo backend over TCP - plumbing, not the product path.
+reduction, the 128-byte RCCL id) is a plain TCP hub on rank 0 - no torch on the product path; torch.distributed's
+gloo group is kept as a second backend for the tests.
 
-`shard_range` and `ControlPlane` are pure host logic and are covered by world_size-2 gloo tests on CPU."""
+`shard_range`, `ControlPlane` and `DataParallelDecoder` are pure host logic and are covered by world_size-2 tests on
+CPU over both backends."""
 
 from __future__ import annotations
 
@@ -27,87 +29,229 @@ def shard_range(n_items: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-class ControlPlane:
-    """Rank/world discovery from the torchrun environment + gloo collectives on small host tensors.
-    world == 1 needs neither torch nor a rendezvous."""
+class _SocketPlane:
+    """Star-topology collectives over TCP on one node: rank 0 is the hub, every collective is "send my item to the hub,
+    get the list of all items back".  Payloads are a few hundred bytes (a 128-byte RCCL id, timings, token ids), so
+    neither bandwidth nor topology matters; what matters is that the product path needs no torch.
 
-    def __init__(self, backend: str = "gloo"):
+    Rendezvous: the launcher (torch.distributed.run, or a test's spawn) exports MASTER_ADDR / MASTER_PORT, but under
+    torchrun that port already belongs to the agent's own store, so the hub binds an ephemeral port and publishes it in a
+    file every local rank can derive: $PGK_CP_DIR (default: the system temp dir) / pgk_cp_<MASTER_PORT>_<run id>.  A
+    stale file from an earlier run names a dead port (connection refused) or a foreign listener (handshake mismatch):
+    either way the client re-reads the file until the deadline.  PGK_CP_PORT forces a fixed hub port instead."""
+
+    MAGIC = b"PGKCP1"
+
+    def __init__(self, rank: int, world: int, timeout_s: float = 300.0):
+        import socket
+        import tempfile
+
+        self.rank, self.world = rank, world
+        self._peers: list = []
+        self._sock = None
+        self._file = None
+        host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        fixed = os.environ.get("PGK_CP_PORT")
+        key = f"pgk_cp_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getuid()}"
+        path = os.path.join(os.environ.get("PGK_CP_DIR", tempfile.gettempdir()), key)
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind(("0.0.0.0" if host not in ("127.0.0.1", "localhost") else "127.0.0.1", int(fixed) if fixed else 0))
+            srv.listen(world)
+            srv.settimeout(timeout_s)
+            nonce = os.urandom(8).hex()
+            if not fixed:
+                tmp = f"{path}.{os.getpid()}"
+                with open(tmp, "w") as f:
+                    f.write(f"{srv.getsockname()[1]} {nonce}\n")
+                os.replace(tmp, path)          # atomic: a reader sees the old file or the new one, never half of it
+                self._file = path
+            self._nonce = nonce
+            peers = {}
+            while len(peers) < world - 1:
+                conn, _ = srv.accept()
+                conn.settimeout(timeout_s)
+                try:
+                    hello = self._recv(conn)
+                except Exception:  # noqa: BLE001 - not one of ours
+                    conn.close()
+                    continue
+                ok = (isinstance(hello, tuple) and len(hello) == 4 and hello[0] == self.MAGIC and hello[2] == world
+                      and (fixed or hello[3] == nonce) and 0 < hello[1] < world and hello[1] not in peers)
+                if not ok:
+                    conn.close()
+                    continue
+                self._send(conn, (self.MAGIC, "ok"))
+                peers[hello[1]] = conn
+            srv.close()
+            self._peers = [peers[r] for r in range(1, world)]
+        else:
+            import time
+
+            deadline = time.monotonic() + timeout_s
+            last = None
+            while True:
+                if time.monotonic() > deadline:
+                    raise TimeoutError(f"control plane: rank {rank} could not reach the hub ({last})")
+                try:
+                    if fixed:
+                        port, nonce = int(fixed), ""
+                    else:
+                        with open(path) as f:
+                            port_s, nonce = f.read().split()
+                        port = int(port_s)
+                    c = socket.create_connection((host, port), timeout=5.0)
+                    c.settimeout(timeout_s)
+                    self._send(c, (self.MAGIC, rank, world, nonce))
+                    reply = self._recv(c)
+                    if reply != (self.MAGIC, "ok"):
+                        raise ConnectionError("handshake refused")
+                    self._sock = c
+                    break
+                except (OSError, ValueError, EOFError, ConnectionError) as e:
+                    last = e
+                    time.sleep(0.05)
+        # collectives may legitimately wait minutes for the slowest rank (weight generation, engine build)
+        for c in self._peers + ([self._sock] if self._sock else []):
+            c.settimeout(float(os.environ.get("PGK_CP_TIMEOUT", "1800")))
+
+    @staticmethod
+    def _send(conn, obj) -> None:
+        import pickle
+        import struct
+
+        data = pickle.dumps(obj, protocol=4)
+        conn.sendall(struct.pack("<Q", len(data)) + data)
+
+    @staticmethod
+    def _recv(conn):
+        import pickle
+        import struct
+
+        def exact(n):
+            buf = bytearray()
+            while len(buf) < n:
+                chunk = conn.recv(n - len(buf))
+                if not chunk:
+                    raise EOFError("control plane: peer closed the connection")
+                buf += chunk
+            return bytes(buf)
+
+        (n,) = struct.unpack("<Q", exact(8))
+        if n > (1 << 28):
+            raise ValueError("control plane: oversized frame")
+        return pickle.loads(exact(n))
+
+    def all_gather(self, item) -> list:
+        """Every rank's item, in rank order, on every rank."""
+        if self.rank == 0:
+            items = [item] + [self._recv(c) for c in self._peers]
+            for c in self._peers:
+                self._send(c, items)
+            return items
+        self._send(self._sock, item)
+        return self._recv(self._sock)
+
+    def close(self) -> None:
+        for c in self._peers + ([self._sock] if self._sock else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self._peers, self._sock = [], None
+        if self._file:
+            try:
+                os.remove(self._file)
+            except OSError:
+                pass
+            self._file = None
+
+
+class ControlPlane:
+    """Rank/world discovery from the launcher's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*) and a handful of
+    collectives on small host values.  world == 1 needs no rendezvous at all.
+
+    backend "socket" (default): the TCP hub above - no torch anywhere on the product path.
+    backend "gloo": torch.distributed's gloo group, kept as the second implementation the CPU tests run the same
+    harness on."""
+
+    def __init__(self, backend: str = "socket"):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+        if backend not in ("socket", "gloo"):
+            raise ValueError(f"ControlPlane: backend {backend!r} not in ('socket', 'gloo')")
+        self.backend = backend
         self._dist = None
+        self._plane = None
         if self.world > 1:
-            import torch.distributed as dist
-
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if not dist.is_initialized():
-                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
-            self._dist = dist
+            if backend == "gloo":
+                import torch.distributed as dist
+
+                if not dist.is_initialized():
+                    dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+                self._dist = dist
+            else:
+                self._plane = _SocketPlane(self.rank, self.world)
+
+    def all_gather_object(self, item) -> list:
+        """Every rank's (picklable) item in rank order."""
+        if self._plane is not None:
+            return self._plane.all_gather(item)
+        if self._dist is not None:
+            outs = [None] * self.world
+            self._dist.all_gather_object(outs, item)
+            return outs
+        return [item]
 
     def barrier(self) -> None:
-        if self._dist is not None:
+        if self._plane is not None:
+            self._plane.all_gather(None)
+        elif self._dist is not None:
             self._dist.barrier()
 
     def max_over_ranks(self, value: float) -> float:
-        if self._dist is None:
-            return float(value)
-        import torch
-
-        t = torch.tensor([float(value)], dtype=torch.float64)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
-        return float(t[0])
+        return float(max(self.all_gather_object(float(value))))
 
     def min_over_ranks(self, value: float) -> float:
-        return -self.max_over_ranks(-float(value))
+        return float(min(self.all_gather_object(float(value))))
+
+    def sum_over_ranks(self, value: float) -> float:
+        return float(sum(self.all_gather_object(float(value))))
 
     def first_note(self, note: str | None) -> str | None:
         """The first non-empty string any rank holds (rank order) - used to report one rank's error on rank 0."""
-        if self._dist is None:
-            return note
-        outs = [None] * self.world
-        self._dist.all_gather_object(outs, note)
-        return next((o for o in outs if o), None)
+        return next((o for o in self.all_gather_object(note) if o), None)
+
+    def broadcast_bytes(self, data: bytes | None, n: int, root: int = 0) -> bytes:
+        """Broadcast an n-byte blob from root (used for the 128-byte RCCL unique id)."""
+        blob = self.all_gather_object(bytes(data) if self.rank == root else None)[root]
+        if len(blob) != n:
+            raise ValueError(f"broadcast_bytes: root sent {len(blob)} bytes, expected {n}")
+        return blob
+
+    def gather_int32(self, local: np.ndarray) -> np.ndarray:
+        """All-gather equal-length int32 vectors over the control plane (CPU test path; RCCL carries them on GPUs)."""
+        local = np.ascontiguousarray(local, dtype=np.int32)
+        parts = self.all_gather_object(local.tobytes())
+        if any(len(p) != local.nbytes for p in parts):
+            raise ValueError("gather_int32: ranks sent vectors of different length")
+        return np.stack([np.frombuffer(p, dtype=np.int32) for p in parts])
 
     def all_gather_array(self, local: np.ndarray) -> list[np.ndarray]:
         """Equal-shape int32 arrays from every rank, over the control plane."""
         flat = self.gather_int32(np.ascontiguousarray(local, dtype=np.int32).ravel())
         return [f.reshape(local.shape) for f in flat]
 
-    def sum_over_ranks(self, value: float) -> float:
-        if self._dist is None:
-            return float(value)
-        import torch
-
-        t = torch.tensor([float(value)], dtype=torch.float64)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
-        return float(t[0])
-
-    def broadcast_bytes(self, data: bytes | None, n: int, root: int = 0) -> bytes:
-        """Broadcast an n-byte blob from root (used for the 128-byte RCCL unique id)."""
-        if self._dist is None:
-            return bytes(data)
-        import torch
-
-        t = torch.zeros(n, dtype=torch.uint8)
-        if self.rank == root:
-            t = torch.frombuffer(bytearray(data), dtype=torch.uint8).clone()
-        self._dist.broadcast(t, src=root)
-        return bytes(t.numpy().tobytes())
-
-    def gather_int32(self, local: np.ndarray) -> np.ndarray:
-        """All-gather equal-length int32 vectors over the control plane (CPU test path / fallback)."""
-        local = np.ascontiguousarray(local, dtype=np.int32)
-        if self._dist is None:
-            return local[None, :]
-        import torch
-
-        outs = [torch.zeros(local.size, dtype=torch.int32) for _ in range(self.world)]
-        self._dist.all_gather(outs, torch.from_numpy(local.copy()))
-        return np.stack([o.numpy() for o in outs])
-
     def shutdown(self) -> None:
+        if self._plane is not None:
+            self._plane.close()
+            self._plane = None
         if self._dist is not None and self._dist.is_initialized():
             self._dist.destroy_process_group()
+        self._dist = None
 
 
 class RcclComm:

@@ -93,11 +93,14 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
                 if constexpr (FP8) psc[r][c] = to_f(a.wscale[(size_t)(row >> 7) * (KC >> 7) + (k0 >> 7)]);
             }
         }
+        // ---- the weights are on their way: now wait for the kernel that produces the activations (dual chain) ----
+        dep_wait(a.dep);
+        // every load of bytes another kernel of this step wrote is an sc1 load (engine_common.cuh)
         if constexpr (EPI == EPI_RESID) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int m = 0; m < M; ++m) resv[r][m] = a.res[(size_t)m * a.ld_out + min(nf + r, N - 1)];
+                for (int m = 0; m < M; ++m) resv[r][m] = ld_sc1_f(a.res + (size_t)m * a.ld_out + min(nf + r, N - 1));
         }
         // ---- prologue, exact trip counts ----
         if constexpr (PRO == PRO_NORM || PRO == PRO_NORM_SUM) {
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
                 const int i = threadIdx.x + 256 * j;
                 gv[j] = to_f(a.gamma[i]);
 #pragma unroll
-                for (int m = 0; m < M; ++m) hv[m][j] = a.h[(size_t)m * KC + i];
+                for (int m = 0; m < M; ++m) hv[m][j] = ld_sc1_f(a.h + (size_t)m * KC + i);
             }
             if constexpr (PRO == PRO_NORM_SUM) {
                 // partial vectors: unconditional clamped loads, masked adds (one round trip for up to 8)
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
                         float pv[NP];
 #pragma unroll
                         for (int p = 0; p < NP; ++p)
-                            pv[p] = a.part[((size_t)m * np + min(p, np - 1)) * KC + threadIdx.x + 256 * j];
+                            pv[p] = ld_sc1_f(a.part + ((size_t)m * np + min(p, np - 1)) * KC + threadIdx.x + 256 * j);
 #pragma unroll
                         for (int p = 0; p < NP; ++p) hv[m][j] += (p < np) ? pv[p] : 0.f;
                     }
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) {
                     const int i = threadIdx.x + 256 * j;
-                    if constexpr (PRO == PRO_NORM_SUM) { if (blockIdx.x == 0) a.h_out[(size_t)m * KC + i] = hv[m][j]; }
+                    if constexpr (PRO == PRO_NORM_SUM) { if (blockIdx.x == 0) st_sc1_f(a.h_out + (size_t)m * KC + i, hv[m][j]); }
                     store_x<XT>(xs, m * KC + i, hv[m][j] * inv * gv[j]);
                 }
             }
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
 #pragma unroll
             for (int m = 0; m < M; ++m)
 #pragma unroll
-                for (int j = 0; j < KJ; ++j) xv[m][j] = a.xin[(size_t)m * KC + threadIdx.x + 256 * j];
+                for (int j = 0; j < KJ; ++j) xv[m][j] = ld_sc1_f(a.xin + (size_t)m * KC + threadIdx.x + 256 * j);
 #pragma unroll
             for (int m = 0; m < M; ++m)
 #pragma unroll
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
 #pragma unroll
                         for (int m = 0; m < M; ++m) {
                             const float gt = acc[r][m], up = acc[r + R / 2][m];
-                            a.out[(size_t)m * a.ld_out + n0 + r] = gt / (1.0f + __expf(-gt)) * up;
+                            st_sc1_f(a.out + (size_t)m * a.ld_out + n0 + r, gt / (1.0f + __expf(-gt)) * up);
                         }
                     }
             } else {
@@ -291,10 +294,12 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
                         for (int m = 0; m < M; ++m) {
                             const size_t o = (size_t)m * a.ld_out + n0 + r;
                             if constexpr (EPI == EPI_RESID) {
-                                const float base = (C > 0 && g == wave) ? resv[r][m] : a.res[o];
-                                a.out[o] = base + acc[r][m];
+                                const float base = (C > 0 && g == wave) ? resv[r][m] : ld_sc1_f(a.res + o);
+                                st_sc1_f(a.out + o, base + acc[r][m]);
+                            } else if constexpr (EPI == EPI_LOGITS) {
+                                a.out[o] = acc[r][m];          // read by later launches only: ordinary stores
                             } else {
-                                a.out[o] = acc[r][m];
+                                st_sc1_f(a.out + o, acc[r][m]);
                             }
                             if constexpr (EPI == EPI_LOGITS) {
                                 if (acc[r][m] > best_v[m]) { best_v[m] = acc[r][m]; best_i[m] = n0 + r; }
@@ -321,6 +326,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
             a.amax_idx[(size_t)m * gridDim.x + blockIdx.x] = bi;
         }
     }
+    dep_signal(a.dep);
     tls.end();
 }
 
@@ -349,7 +355,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* amax_val, co
                                                        const bf16* embed, float* h, int H, int bump,
                                                        unsigned long long* clk_log, const float* rope_cos,
                                                        const float* rope_sin, float* cur_cos, float* cur_sin, int half,
-                                                       int max_seq, int M, const int32_t* sampled, unsigned long long* tl) {
+                                                       int max_seq, int M, const int32_t* sampled, unsigned* dep_epoch,
+                                                       unsigned long long* tl) {
     const TLStamp tls(tl);
     __shared__ float sv[4];
     __shared__ int si[4];
@@ -413,11 +420,15 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* amax_val, co
         cur_sin[(size_t)b * half + i] = rope_sin[(size_t)s_pos * half + i];
     }
     if (bump && threadIdx.x == 0) {
+        // dep_epoch: steps completed, the base of the dual chain's arrival-counter targets (never reset, unlike the log's
+        // step counter); every kernel of the NEXT step is launched behind this one
         if (M == 1) {
             step_counter[0] = step + 1;
+            if (dep_epoch) dep_epoch[0] += 1u;
         } else if (atomicAdd(&step_counter[1], 1) == M - 1) {   // every workgroup has read `step` before its own ticket
             atomicExch(&step_counter[1], 0);
             step_counter[0] = step + 1;
+            if (dep_epoch) dep_epoch[0] += 1u;
         }
     }
     tls.end();
@@ -447,6 +458,7 @@ struct AttnArgs {
     int H, rows_per_block;
     float* opart;         // [B][Hkv][H]
     bf16* attn_direct16;  // whole-context variant: bf16 output instead of attn_direct (batched MFMA o_proj reads it)
+    DepArgs dep;          // dual-chain step (attn_oproj_kernel only); all null otherwise
 };
 
 template <int D, int G>
@@ -466,10 +478,9 @@ __device__ __forceinline__ void prepare_new_token(const AttnArgs& a, int b, int 
     float raw[G + 2][8], gq[8], gk[8], csv[8], snv[8];
 #pragma unroll
     for (int g = 0; g < G + 2; ++g) {
-        const float* src = (g < G) ? row + (size_t)(kvh * G + g) * D
-                                   : (g == G ? row + (size_t)a.hq * D + (size_t)kvh * D
-                                             : row + (size_t)(a.hq + a.hkv) * D + (size_t)kvh * D);
-        const float4 u = *reinterpret_cast<const float4*>(src + sub * 8), v = *reinterpret_cast<const float4*>(src + sub * 8 + 4);
+        // q/k/v come from the previous kernel of this step: sc1 loads (dual chain, engine_common.cuh)
+        const unsigned eoff = (g < G) ? (unsigned)(kvh * G + g) * D : (g == G ? (unsigned)(a.hq + kvh) * D : (unsigned)(a.hq + a.hkv + kvh) * D);
+        const float4 u = ld_sc1_f4(row, (eoff + sub * 8) * 4u), v = ld_sc1_f4(row, (eoff + sub * 8 + 4) * 4u);
         raw[g][0] = u.x; raw[g][1] = u.y; raw[g][2] = u.z; raw[g][3] = u.w;
         raw[g][4] = v.x; raw[g][5] = v.y; raw[g][6] = v.z; raw[g][7] = v.w;
     }
@@ -729,6 +740,7 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a, unsigned lo
     KVBatch<U0> kb0;
     kv_issue<D, U0, NWV>(kb0, a.kcache + head_off, a.vcache + head_off, wid * PPW, a.max_seq - 1, lane);
     const int pos = a.positions[b];
+    dep_wait(a.dep);        // W_o slice and the cached K/V rows are in flight; q/k/v of this step come from the qkv kernel
     NewToken<D, G> t;
     prepare_new_token<D, G>(a, b, kvh, pos, lane, t);
     if (blockIdx.x == 0 && pos < a.max_seq && wid == 0 && lane < LPR) {
@@ -759,8 +771,9 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a, unsigned lo
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc = fmaf(wf[j], xf[j], acc);
         acc = group_sum<LPW>(acc);
-        if (lr == 0) outp[row] = acc;
+        if (lr == 0) st_sc1_f(outp + row, acc);
     }
+    dep_signal(a.dep);
     tls.end();
 }
 
@@ -1004,6 +1017,12 @@ struct Engine {
           *amax_val = nullptr;
     int* amax_idx = nullptr;
     unsigned long long* clk_log = nullptr;
+    // dual-chain step (engine_common.cuh): arrival counters [4 L][DEP_SHARDS x DEP_STRIDE], the epoch word, the error word,
+    // and the second capture branch
+    unsigned *dep_cnt = nullptr, *dep_epoch = nullptr, *dep_err = nullptr;
+    bool dual_ok = false;           // shapes suit it and PGK_DUAL_CHAIN != 0
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t kv_bytes = 0, ws_bytes = 0;
     // prefill workspace (grown on demand, outside capture)
     void* pf = nullptr;
@@ -1030,8 +1049,11 @@ static pgk_status dev_alloc(Engine* e, void** p, size_t bytes, size_t* acct) {
 }
 
 
+static thread_local int g_last_grid = 0;     // workgroups of the most recent fused / attention launch (dual-chain wiring)
+
 template <class WT, class XT, int M, int R, int PRO, int EPI, int C>
 static pgk_status launch_fused_c(const FusedArgs& a, int n_out, hipStream_t st, int force_grid) {
+    PGK_REQUIRE(C > 0 || (a.dep.wait_cnt == nullptr && a.dep.sig_cnt == nullptr), "engine: dual-chain step on a run-time-K GEMV (K=%d)", a.K);
     constexpr int OUT_PER_TRIP = (EPI == EPI_SWIGLU) ? R / 2 : R;
     const size_t lds = (size_t)M * a.K * sizeof(XT);
     PGK_REQUIRE(lds <= 156 * 1024, "engine: %d activation rows of K=%d do not fit LDS", M, a.K);
@@ -1043,6 +1065,7 @@ static pgk_status launch_fused_c(const FusedArgs& a, int n_out, hipStream_t st, 
     }
     int grid = force_grid ? force_grid : ceil_div(n_out, OUT_PER_TRIP * 4);
     if (grid > 1024) grid = 1024;
+    g_last_grid = grid;
     PGK_CHECK_HIP(launch_k(kfn, dim3(grid), dim3(256), lds, st, a));
     return PGK_OK;
 }
@@ -1075,7 +1098,8 @@ static pgk_status launch_fused_auto(const FusedArgs& a, int n_out, hipStream_t s
 }
 
 template <int D>
-static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, hipStream_t st, bool direct_bf16 = false) {
+static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, hipStream_t st, bool direct_bf16 = false,
+                              const DepArgs* dep = nullptr) {
     const auto& c = e->cfg;
     const auto& L = e->layers[layer];
     const int G = c.num_heads / c.num_kv_heads;
@@ -1111,6 +1135,8 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
     const bool inmerge = !fused && !direct && e->merge_cnt != nullptr;
     if (inmerge) { a.merge_counter = e->merge_cnt + (size_t)b0 * c.num_kv_heads; a.attn_merged = e->attnv + (size_t)b0 * c.num_heads * D; }
     dim3 grid = fused ? dim3(c.hidden_size / e->oproj_rows, c.num_kv_heads, m) : dim3(a.nsplit, c.num_kv_heads, m);
+    if (dep && fused) a.dep = *dep;
+    g_last_grid = (int)(grid.x * grid.y * grid.z);
     hipError_t he = hipSuccess;
 #define PGK_ATTN(GG)                                                               \
     case GG:                                                                       \
@@ -1143,8 +1169,12 @@ static pgk_status engine_sample(Engine* e, int b0, int M, hipStream_t st) {
                             e->sample_top_p, e->u_ring + b0, e->u_cap, e->cfg.max_batch, e->step_counter, e->sampled + b0, e->sample_scratch, st);
 }
 
+// `dual`: wire the 4 L layer kernels into the dual chain (engine_common.cuh) - every kernel waits for its predecessor on
+// a device counter instead of relying on stream order.  With st2 != st (graph capture) consecutive kernels alternate
+// between the two capture branches and overlap; with st2 == st (eager) the same kernels run back to back and every wait
+// is already satisfied.  Only single-chunk steps on the fused short-context path qualify (decode_step_impl).
 template <class WT, class XT, int M>
-static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int* launches) {
+static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int* launches, bool dual = false, hipStream_t st2 = nullptr) {
     const auto& c = e->cfg;
     const int H = c.hidden_size, I = c.intermediate_size, D = c.head_dim, QD = c.num_heads * D, NQKV = e->qkv_dim();
     float* h = e->h + (size_t)b0 * H;
@@ -1152,6 +1182,27 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
     // fused attention+o_proj recomputes a KV head's attention in every row-slice workgroup: right for one or
     // two sequences at short context, wasteful for a batch - batches take the split-KV path.
     const bool fused = e->fused_attn && M <= 2;
+    dual = dual && fused && !e->skip_attn;
+    const bool two = dual && st2 && st2 != st;
+    hipStream_t sA = st, sB = two ? st2 : st;
+    if (two) {   // fork: the second branch starts behind everything already enqueued on the first
+        PGK_CHECK_HIP(hipEventRecord(e->ev_fork, st));
+        PGK_CHECK_HIP(hipStreamWaitEvent(st2, e->ev_fork, 0));
+    }
+    unsigned prev_wgs = 0;
+    int kidx = 0;
+    auto wire = [&]() -> DepArgs {
+        DepArgs d{};
+        if (dual) {
+            d.sig_cnt = e->dep_cnt + (size_t)kidx * DEP_SHARDS * DEP_STRIDE;
+            d.wait_cnt = kidx > 0 ? e->dep_cnt + (size_t)(kidx - 1) * DEP_SHARDS * DEP_STRIDE : nullptr;
+            d.wait_per_step = prev_wgs;
+            d.epoch = e->dep_epoch;
+            d.err = e->dep_err;
+        }
+        return d;
+    };
+    auto launched = [&]() { prev_wgs = (unsigned)g_last_grid; ++kidx; };
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& L = e->layers[l];
         FusedArgs a{};
@@ -1160,12 +1211,16 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
         a.w = L.w_qkv; a.wscale = (const bf16*)L.s_qkv; a.N = NQKV; a.K = H;
         a.h = h; a.gamma = (const bf16*)L.attn_norm; a.eps = c.norm_eps;
         a.out = e->qkv + (size_t)b0 * NQKV; a.ld_out = NQKV;
-        if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM, EPI_STORE>(a, NQKV, st)) return r;
+        a.dep = wire();
+        if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM, EPI_STORE>(a, NQKV, sA)) return r;
+        launched();
         mark(KC_ATTN);
         // 2. attention (QK-norm, RoPE, KV write fused; on the fused path also the o_proj partial products)
         if (!e->skip_attn) {
-            if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, fused, st)) return r; }
-            else { if (pgk_status r = launch_attn<64>(e, l, b0, M, fused, st)) return r; }
+            const DepArgs d = wire();
+            if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, fused, sB, false, &d)) return r; }
+            else { if (pgk_status r = launch_attn<64>(e, l, b0, M, fused, sB, false, &d)) return r; }
+            launched();
         }
         const float* mlp_in = h;
         if (!fused) {
@@ -1176,6 +1231,7 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
             a.xin = e->attnv + (size_t)b0 * QD;
             a.res = h; a.out = h; a.ld_out = H;
             if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_PLAIN, EPI_RESID>(a, H, st)) return r;
+            launched();
             *launches += ((e->attn_direct_ok && M >= 3) || e->merge_cnt) ? 1 : 2;   // o_proj (+ the merge kernel unless attention normalised in place)
         }
         // 4. act = silu(Wg x) * (Wu x), x = rmsnorm(h [+ sum of o_proj partials])
@@ -1188,13 +1244,16 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
         if constexpr (M <= 2) {   // the fused path only ever runs for one or two sequences per chunk
             if (fused) {
                 a.part = e->opart + (size_t)b0 * c.num_kv_heads * H; a.nsplit = c.num_kv_heads; a.h_out = h2;
-                if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM_SUM, EPI_SWIGLU>(a, I, st)) return r;
+                a.dep = wire();
+                if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM_SUM, EPI_SWIGLU>(a, I, sA)) return r;
+                launched();
                 mlp_in = h2;
                 done_gateup = true;
             }
         }
         if (!done_gateup) {
             if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM, EPI_SWIGLU>(a, I, st)) return r;
+            launched();
         }
         // 5. h = mlp_in + Wd . act
         mark(KC_DOWN);
@@ -1202,8 +1261,14 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
         a.w = L.w_down; a.wscale = (const bf16*)L.s_down; a.N = H; a.K = I;
         a.xin = e->act + (size_t)b0 * I;
         a.res = mlp_in; a.out = h; a.ld_out = H;
-        if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_PLAIN, EPI_RESID>(a, H, st)) return r;
+        a.dep = wire();
+        if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_PLAIN, EPI_RESID>(a, H, sB)) return r;
+        launched();
         *launches += 4;
+    }
+    if (two) {   // join: lm_head and everything after it are ordinary successors of BOTH branches
+        PGK_CHECK_HIP(hipEventRecord(e->ev_join, st2));
+        PGK_CHECK_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
     }
     // logits = E . rmsnorm(h)  (lm_head stays bf16 even when the linears are fp8)
     mark(KC_LMHEAD);
@@ -1224,7 +1289,7 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
                                        e->lm_blocks, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
                                        e->cfg.max_batch, e->log_cap, e->embed, h, H, last ? 1 : 0, b0 == 0 ? e->clk_log : nullptr,
                                        e->rope_cos, e->rope_sin, e->cur_cos + (size_t)b0 * (D / 2), e->cur_sin + (size_t)b0 * (D / 2),
-                                       D / 2, c.max_seq_len, M, sampled));
+                                       D / 2, c.max_seq_len, M, sampled, dual ? e->dep_epoch : (unsigned*)nullptr));
     *launches += 2;
     return PGK_OK;
 }
@@ -1312,14 +1377,15 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
     PGK_CHECK_HIP(launch_k(finalize_kernel, dim3(M), dim3(256), 0, st, a.amax_val, a.amax_idx, nblk, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
                                        e->cfg.max_batch, e->log_cap, e->embed, h, H, last ? 1 : 0, b0 == 0 ? e->clk_log : nullptr,
                                        e->rope_cos, e->rope_sin, e->cur_cos + (size_t)b0 * (D / 2), e->cur_sin + (size_t)b0 * (D / 2),
-                                       D / 2, c.max_seq_len, M, sampled));
+                                       D / 2, c.max_seq_len, M, sampled, (unsigned*)nullptr));
     *launches += 2;
     return PGK_OK;
 }
 
 template <class WT>
-static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* launches) {
+static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* launches, hipStream_t st2) {
     int b0 = 0;
+    const bool dual = e->dual_ok && batch <= 2;      // one chunk of one or two sequences on the fused path
     while (b0 < batch) {
         const int rem = batch - b0;
         pgk_status r;
@@ -1330,16 +1396,17 @@ static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* la
         if (mfma_ok) { const int m = rem > e->batched_max ? e->batched_max : rem; r = decode_chunk_batched<WT>(e, b0, m, rem == m, st, launches); b0 += m; }
         else if (rem >= 8) { r = decode_chunk<WT, bf16, 8>(e, b0, rem == 8, st, launches); b0 += 8; }
         else if (rem >= 4) { r = decode_chunk<WT, bf16, 4>(e, b0, rem == 4, st, launches); b0 += 4; }
-        else if (rem >= 2) { r = decode_chunk<WT, float, 2>(e, b0, rem == 2, st, launches); b0 += 2; }
-        else { r = decode_chunk<WT, float, 1>(e, b0, true, st, launches); b0 += 1; }
+        else if (rem >= 2) { r = decode_chunk<WT, float, 2>(e, b0, rem == 2, st, launches, dual && batch == 2, st2); b0 += 2; }
+        else { r = decode_chunk<WT, float, 1>(e, b0, true, st, launches, dual && batch == 1, st2); b0 += 1; }
         if (r != PGK_OK) return r;
     }
     return PGK_OK;
 }
 
-static pgk_status decode_step(Engine* e, int batch, hipStream_t st, int* launches) {
-    if (e->cfg.weight_format != 0) return decode_step_impl<fp8e4m3>(e, batch, st, launches);
-    return decode_step_impl<bf16>(e, batch, st, launches);
+// st2: second capture branch for the dual chain (null / == st: everything on st)
+static pgk_status decode_step(Engine* e, int batch, hipStream_t st, int* launches, hipStream_t st2 = nullptr) {
+    if (e->cfg.weight_format != 0) return decode_step_impl<fp8e4m3>(e, batch, st, launches, st2);
+    return decode_step_impl<bf16>(e, batch, st, launches, st2);
 }
 
 }  // namespace pgk
@@ -1444,6 +1511,30 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
     A((void**)&e->amax_val, (size_t)B * e->lm_cap * 4, &e->ws_bytes);
     A((void**)&e->amax_idx, (size_t)B * e->lm_cap * 4, &e->ws_bytes);
     A((void**)&e->clk_log, (size_t)e->log_cap * 16, &e->ws_bytes);
+    {
+        // dual-chain step: counters for the 4 L layer kernels + epoch + error word, one allocation, zeroed once
+        const size_t words = (size_t)4 * c.num_layers * DEP_SHARDS * DEP_STRIDE + 2 * DEP_STRIDE;
+        A((void**)&e->dep_cnt, words * 4, &e->ws_bytes);
+        if (r == PGK_OK) {
+            e->dep_epoch = e->dep_cnt + (size_t)4 * c.num_layers * DEP_SHARDS * DEP_STRIDE;
+            e->dep_err = e->dep_epoch + DEP_STRIDE;
+            if (hipMemset(e->dep_cnt, 0, words * 4) != hipSuccess) r = set_error(PGK_ERR_HIP, "pgk_engine_create: hipMemset of the dual-chain counters failed");
+        }
+        // every GEMV of the fused step must take its compile-time-K instance (the one that preloads its weights and
+        // knows how to wait): K = 512 C with C in {1,2,3,4,6} and C x rows-per-wave <= 8
+        auto c_ok = [](int K, int R) { const int cc = K / 512; return K % 512 == 0 && (cc == 1 || cc == 2 || cc == 3 || cc == 4 || cc == 6) && cc * R <= 8; };
+        const int nq = e->qkv_dim();
+        const int r_qkv = nq >= 4096 ? 4 : (nq >= 2048 ? 2 : 1), r_gu = c.intermediate_size >= 4096 ? 4 : 2;
+        const int r_dn = c.hidden_size >= 4096 ? 4 : (c.hidden_size >= 2048 ? 2 : 1);
+        const char* ed = getenv("PGK_DUAL_CHAIN");
+        e->dual_ok = !(ed && atoi(ed) == 0) && e->fused_attn && c.weight_format == 0 && c_ok(c.hidden_size, r_qkv) && c_ok(c.hidden_size, r_gu) &&
+                     c_ok(c.intermediate_size, r_dn);
+        if (e->dual_ok && r == PGK_OK) {
+            if (hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess)
+                e->dual_ok = false;
+        }
+    }
     if (r != PGK_OK) { pgk_engine_destroy(e); return r; }
     // RoPE tables in fp32, same formula as the reference (src/pygpukit/llm/layers/rope.py:13-24):
     // freqs = 1/theta^(2i/D) in fp32, angle = float(t) * freq in fp32, cos/sin of that.
@@ -1479,6 +1570,9 @@ pgk_status pgk_engine_destroy(pgk_engine eh) {
     Engine* e = (Engine*)eh;
     if (e->exec) (void)hipGraphExecDestroy(e->exec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->st2) (void)hipStreamDestroy(e->st2);
     for (void* p : e->allocs) (void)pgk_free(p);
     if (e->pf) (void)pgk_free(e->pf);
     if (e->pf_tokens) (void)pgk_free(e->pf_tokens);
@@ -1723,7 +1817,7 @@ pgk_status pgk_engine_timeline(pgk_engine eh, int batch, int warm, uint64_t* h_o
     if (he == hipSuccess) {
         g_probe = &probe;
         int launches = 0;
-        r = decode_step(e, batch, st, &launches);
+        r = decode_step(e, batch, st, &launches, e->dual_ok ? e->st2 : nullptr);
         g_probe = nullptr;
         he = hipStreamEndCapture(st, &g);
     }
@@ -1773,7 +1867,7 @@ pgk_status pgk_engine_capture(pgk_engine eh, int batch, pgk_stream s) {
     if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
     PGK_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
     int launches = 0;
-    pgk_status r = decode_step(e, batch, st, &launches);
+    pgk_status r = decode_step(e, batch, st, &launches, e->dual_ok ? e->st2 : nullptr);
     hipGraph_t g = nullptr;
     hipError_t he = hipStreamEndCapture(st, &g);
     if (r != PGK_OK) { if (g) (void)hipGraphDestroy(g); return r; }
@@ -1808,9 +1902,13 @@ pgk_status pgk_engine_read_tokens(pgk_engine eh, int32_t* h_out, int batch, int 
     hipStream_t st = resolve_stream(s);
     // log rows are max_batch wide; return the first `batch` columns, step-major
     std::vector<int32_t> tmp((size_t)n_steps * e->cfg.max_batch);
-    if (n_steps) {
-        PGK_CHECK_HIP(hipMemcpyAsync(tmp.data(), e->token_log, tmp.size() * 4, hipMemcpyDeviceToHost, st));
-        PGK_CHECK_HIP(hipStreamSynchronize(st));
+    unsigned dep_err = 0;
+    PGK_CHECK_HIP(hipMemcpyAsync(&dep_err, e->dep_err, 4, hipMemcpyDeviceToHost, st));
+    if (n_steps) PGK_CHECK_HIP(hipMemcpyAsync(tmp.data(), e->token_log, tmp.size() * 4, hipMemcpyDeviceToHost, st));
+    PGK_CHECK_HIP(hipStreamSynchronize(st));
+    if (dep_err) {
+        (void)hipMemsetAsync(e->dep_err, 0, 4, st);
+        return set_error(PGK_ERR_HIP, "pgk_engine_read_tokens: a dual-chain wait timed out during the last steps (tokens invalid); set PGK_DUAL_CHAIN=0");
     }
     for (int t = 0; t < n_steps; ++t)
         for (int b = 0; b < batch; ++b) h_out[(size_t)t * batch + b] = tmp[(size_t)t * e->cfg.max_batch + b];

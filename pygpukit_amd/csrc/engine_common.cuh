@@ -92,6 +92,78 @@ struct TLStamp {
     }
 };
 
+// --------------------------------------------------------------------------------------------
+// Dual-chain decode step: overlap of dependent kernels (engine.hip, decode_chunk).
+//
+// A batch-1 token is a chain of 4 L dependent weight-streaming kernels of 1-2 us of streaming each; run back to back
+// on one stream every link costs a dispatch boundary + the grid's ramp + one cold HBM round trip before the first
+// useful byte (~3 us of a ~5 us kernel).  In the dual chain consecutive kernels alternate between two graph branches, so
+// kernel k+1 is dispatched WHILE kernel k runs: its workgroups issue their weight loads (which depend on nothing),
+// then wait for kernel k on a device counter, then read the activation vector and finish.  Protocol per the CDNA guide's
+// inter-workgroup rules (Guideline 16, table row "one lane of each storing workgroup ... atomic add / sc1 poll"):
+//   producer  every activation store is write-through (`sc1`), every storing wave drains (`s_waitcnt vmcnt(0)`), the
+//             workgroup meets, ONE lane adds 1 to the kernel's arrival counter (8 shards on separate 64-byte lines);
+//   consumer  one wave polls the 8 shards with relaxed agent-scope loads until they sum to (steps so far + 1) x the
+//             producer's workgroup count, the workgroup meets, and EVERY load of producer-written bytes is an `sc1`
+//             load (L1 is bypassed; no acquire fence needed).  Read-only data (weights, gammas) use ordinary loads.
+// Counters only ever grow (the step count comes from a device word the step's last kernel bumps), so nothing is reset
+// between replays.  Every spin is bounded: on timeout the waiter sets the error word and goes on (wrong numbers, no hang);
+// the host checks the word whenever it synchronises.  Deadlock-freedom: a spinning kernel never occupies the whole chip
+// (its grid x registers is < 70 % of the register file), and its producer was dispatched before it.
+struct DepArgs {
+    const unsigned* wait_cnt;   // predecessor's arrival counters (shard s at [16 s]), or null
+    unsigned wait_per_step;     // workgroups of the predecessor per step
+    unsigned* sig_cnt;          // this kernel's arrival counters, or null
+    const unsigned* epoch;      // [0] = steps completed so far
+    unsigned* err;              // [0] |= 1 when a wait timed out
+};
+constexpr int DEP_SHARDS = 8, DEP_STRIDE = 16;      // dwords between shards: one 64-byte line each
+constexpr int DEP_SPIN_MAX = 1 << 14;               // x (one L2 round trip + s_sleep) ~ 10-20 ms before a waiter gives up
+
+__device__ __forceinline__ float ld_sc1_f(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_sc1_f(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 16-byte sc1 load: `base` wave-uniform, byte offset per lane (buffer_load_dwordx4 ... offen sc1)
+__device__ __forceinline__ float4 ld_sc1_f4(const float* base, unsigned byte_off) {
+    typedef unsigned dep_u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+    const dep_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);   // aux 16 = sc1
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void dep_wait(const DepArgs& d) {
+    if (d.wait_cnt) {
+        if (threadIdx.x < 64) {
+            const unsigned target = (d.epoch[0] + 1u) * d.wait_per_step;
+            const unsigned* p = d.wait_cnt + (threadIdx.x & (DEP_SHARDS - 1)) * DEP_STRIDE;
+            bool ok = false;
+            for (int spin = 0; spin < DEP_SPIN_MAX; ++spin) {
+                unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64);
+                if ((int)(v - target) >= 0) { ok = true; break; }     // every lane holds the same sum: wave-uniform
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok && threadIdx.x == 0) atomicOr(d.err, 1u);
+        }
+        __syncthreads();
+    }
+}
+// call after the kernel's last activation store, by ALL threads of the workgroup
+__device__ __forceinline__ void dep_signal(const DepArgs& d) {
+    if (d.sig_cnt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            __hip_atomic_fetch_add(d.sig_cnt + (wg & (DEP_SHARDS - 1)) * DEP_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 enum { PRO_NORM = 0, PRO_PLAIN = 1, PRO_ATTN = 2, PRO_NORM_SUM = 3 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3 };
 
@@ -115,6 +187,7 @@ struct FusedArgs {
     // does it once and every consuming workgroup reads half the bytes)
     const bf16* xin16;    // PRO_PLAIN: [M][K] bf16, used instead of xin when set
     bf16* out16;          // EPI_SWIGLU: [M][ld_out] bf16, written instead of out when set
+    DepArgs dep;          // dual-chain step (GEMV kernels with compile-time K only); all null otherwise
 };
 
 // engine_batched.hip: projections for 3..64 sequences on MFMA.  `pro`/`epi` are the codes above; `fp8` selects e4m3

@@ -418,6 +418,9 @@ pgk_status pgk_engine_set_sampling(pgk_engine e, float temperature, int top_k, f
  * step's last kernel: the in-kernel shader clock between two steps is d(memtime)/d(memrealtime) x 100 MHz
  * (MI355X_MICROARCH.md, DVFS give-back item 6).  h_out: uint64[2 * n_steps]. */
 pgk_status pgk_engine_read_clock(pgk_engine e, uint64_t* h_out, int n_steps, pgk_stream s);
+/* Diagnostic for the dual-chain step (consecutive layer kernels on two graph branches, hand-offs through device
+ * counters): h_out[0] = steps completed, [1] = non-zero if a wait ever timed out, [2 + k] = arrivals of layer kernel k. */
+pgk_status pgk_engine_dep_state(pgk_engine e, uint32_t* h_out, int n);
 /* KV cache access for parity tests: pointers to layer `l`'s K and V caches [max_batch,Hkv,max_seq,D] bf16 */
 pgk_status pgk_engine_kv_ptr(pgk_engine e, int layer, void** k, void** v);
 /* device int32[max_batch] arrays holding each sequence's current token and position (the step's inputs and,

@@ -53,7 +53,9 @@ template <> __device__ __forceinline__ void store_x<bf16>(bf16* xs, int i, float
 // (A load under a per-lane guard, or accumulated inside a conditional, is waited for on the spot by
 // hipcc: that serialised dozens of memory round trips per kernel in the first version.)  C == 0 is the
 // generic any-K path.
-template <class WT, class XT, int M, int R, int PRO, int EPI, int C>
+// DUAL: the instance wired into a dual chain (engine_common.cuh): waits for its predecessor after the weight preload, reads
+// and writes activations with sc1 accesses, signals at the end.  A separate instance, so the ordinary step pays nothing.
+template <class WT, class XT, int M, int R, int PRO, int EPI, int C, bool DUAL = false>
 __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned long long* tl) {
     const TLStamp tls(tl);
     constexpr int NW = WTraits<WT>::NW;
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
     __shared__ int s_bi[4][M];
     const int K = (C > 0) ? KC : a.K;
     const int N = a.N;
+    constexpr bool coh = DUAL;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     constexpr int OUT_PER_TRIP = (EPI == EPI_SWIGLU) ? R / 2 : R;
     const int wave = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
@@ -94,13 +97,13 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
             }
         }
         // ---- the weights are on their way: now wait for the kernel that produces the activations (dual chain) ----
-        dep_wait(a.dep);
-        // every load of bytes another kernel of this step wrote is an sc1 load (engine_common.cuh)
+        if constexpr (DUAL) dep_wait(a.dep);
+        // dual chain: every load of bytes another kernel of this step wrote is an sc1 load (engine_common.cuh)
         if constexpr (EPI == EPI_RESID) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int m = 0; m < M; ++m) resv[r][m] = ld_sc1_f(a.res + (size_t)m * a.ld_out + min(nf + r, N - 1));
+                for (int m = 0; m < M; ++m) resv[r][m] = ld_act(a.res + (size_t)m * a.ld_out + min(nf + r, N - 1), coh);
         }
         // ---- prologue, exact trip counts ----
         if constexpr (PRO == PRO_NORM || PRO == PRO_NORM_SUM) {
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
                 const int i = threadIdx.x + 256 * j;
                 gv[j] = to_f(a.gamma[i]);
 #pragma unroll
-                for (int m = 0; m < M; ++m) hv[m][j] = ld_sc1_f(a.h + (size_t)m * KC + i);
+                for (int m = 0; m < M; ++m) hv[m][j] = ld_act(a.h + (size_t)m * KC + i, coh);
             }
             if constexpr (PRO == PRO_NORM_SUM) {
                 // partial vectors: unconditional clamped loads, masked adds (one round trip for up to 8)
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
                         float pv[NP];
 #pragma unroll
                         for (int p = 0; p < NP; ++p)
-                            pv[p] = ld_sc1_f(a.part + ((size_t)m * np + min(p, np - 1)) * KC + threadIdx.x + 256 * j);
+                            pv[p] = ld_act(a.part + ((size_t)m * np + min(p, np - 1)) * KC + threadIdx.x + 256 * j, coh);
 #pragma unroll
                         for (int p = 0; p < NP; ++p) hv[m][j] += (p < np) ? pv[p] : 0.f;
                     }
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) {
                     const int i = threadIdx.x + 256 * j;
-                    if constexpr (PRO == PRO_NORM_SUM) { if (blockIdx.x == 0) st_sc1_f(a.h_out + (size_t)m * KC + i, hv[m][j]); }
+                    if constexpr (PRO == PRO_NORM_SUM) { if (blockIdx.x == 0) st_act(a.h_out + (size_t)m * KC + i, hv[m][j], coh); }
                     store_x<XT>(xs, m * KC + i, hv[m][j] * inv * gv[j]);
                 }
             }
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
 #pragma unroll
             for (int m = 0; m < M; ++m)
 #pragma unroll
-                for (int j = 0; j < KJ; ++j) xv[m][j] = ld_sc1_f(a.xin + (size_t)m * KC + threadIdx.x + 256 * j);
+                for (int j = 0; j < KJ; ++j) xv[m][j] = ld_act(a.xin + (size_t)m * KC + threadIdx.x + 256 * j, coh);
 #pragma unroll
             for (int m = 0; m < M; ++m)
 #pragma unroll
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
 #pragma unroll
                         for (int m = 0; m < M; ++m) {
                             const float gt = acc[r][m], up = acc[r + R / 2][m];
-                            st_sc1_f(a.out + (size_t)m * a.ld_out + n0 + r, gt / (1.0f + __expf(-gt)) * up);
+                            st_act(a.out + (size_t)m * a.ld_out + n0 + r, gt / (1.0f + __expf(-gt)) * up, coh);
                         }
                     }
             } else {
@@ -294,12 +297,12 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
                         for (int m = 0; m < M; ++m) {
                             const size_t o = (size_t)m * a.ld_out + n0 + r;
                             if constexpr (EPI == EPI_RESID) {
-                                const float base = (C > 0 && g == wave) ? resv[r][m] : ld_sc1_f(a.res + o);
-                                st_sc1_f(a.out + o, base + acc[r][m]);
+                                const float base = (C > 0 && g == wave) ? resv[r][m] : ld_act(a.res + o, coh);
+                                st_act(a.out + o, base + acc[r][m], coh);
                             } else if constexpr (EPI == EPI_LOGITS) {
                                 a.out[o] = acc[r][m];          // read by later launches only: ordinary stores
                             } else {
-                                st_sc1_f(a.out + o, acc[r][m]);
+                                st_act(a.out + o, acc[r][m], coh);
                             }
                             if constexpr (EPI == EPI_LOGITS) {
                                 if (acc[r][m] > best_v[m]) { best_v[m] = acc[r][m]; best_i[m] = n0 + r; }
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
             a.amax_idx[(size_t)m * gridDim.x + blockIdx.x] = bi;
         }
     }
-    dep_signal(a.dep);
+    if constexpr (DUAL) dep_signal(a.dep);
     tls.end();
 }
 
@@ -467,11 +470,12 @@ struct NewToken {
     uint4 kbits, vbits;
 };
 
-template <int D, int G>
+template <int D, int G, bool COH = false>
 __device__ __forceinline__ void prepare_new_token(const AttnArgs& a, int b, int kvh, int pos, int lane, NewToken<D, G>& t) {
     constexpr int LPR = D / 8, HALF = D / 2;
     const int sub = lane % LPR;
     const float* row = a.qkv + (size_t)b * a.qkv_ld;
+    constexpr bool coh = COH;
     const float* cs = a.rope_cos + (size_t)b * HALF;   // address independent of pos: no extra round trip
     const float* sn = a.rope_sin + (size_t)b * HALF;
     // all loads first (q heads, k, v, gammas, rope row): one memory round trip, then pure ALU
@@ -480,7 +484,7 @@ __device__ __forceinline__ void prepare_new_token(const AttnArgs& a, int b, int 
     for (int g = 0; g < G + 2; ++g) {
         // q/k/v come from the previous kernel of this step: sc1 loads (dual chain, engine_common.cuh)
         const unsigned eoff = (g < G) ? (unsigned)(kvh * G + g) * D : (g == G ? (unsigned)(a.hq + kvh) * D : (unsigned)(a.hq + a.hkv + kvh) * D);
-        const float4 u = ld_sc1_f4(row, (eoff + sub * 8) * 4u), v = ld_sc1_f4(row, (eoff + sub * 8 + 4) * 4u);
+        const float4 u = ld_act4(row, eoff + sub * 8, coh), v = ld_act4(row, eoff + sub * 8 + 4, coh);
         raw[g][0] = u.x; raw[g][1] = u.y; raw[g][2] = u.z; raw[g][3] = u.w;
         raw[g][4] = v.x; raw[g][5] = v.y; raw[g][6] = v.z; raw[g][7] = v.w;
     }
@@ -711,7 +715,7 @@ __global__ void attn_merge_kernel(const float* part, float* attn, int hq, int ns
 // fused path: grid (H / rows_per_block, Hkv, batch), 256 threads.  Every workgroup of a KV head recomputes
 // that head's (short-context) attention from L2-resident K/V, then multiplies it with ITS slice of W_o
 // (rows_per_block output rows x G*D columns), whose loads were issued before anything else.
-template <int D, int G>
+template <int D, int G, bool DUAL = false>
 __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a, unsigned long long* tl) {
     const TLStamp tls(tl);
     constexpr int NWV = 4;   // 8 waves measured slower: the kernel is issue-bound per SIMD, not per wave
@@ -740,9 +744,9 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a, unsigned lo
     KVBatch<U0> kb0;
     kv_issue<D, U0, NWV>(kb0, a.kcache + head_off, a.vcache + head_off, wid * PPW, a.max_seq - 1, lane);
     const int pos = a.positions[b];
-    dep_wait(a.dep);        // W_o slice and the cached K/V rows are in flight; q/k/v of this step come from the qkv kernel
+    if constexpr (DUAL) dep_wait(a.dep);   // W_o slice and the cached K/V rows are in flight; q/k/v of this step come from the qkv kernel
     NewToken<D, G> t;
-    prepare_new_token<D, G>(a, b, kvh, pos, lane, t);
+    prepare_new_token<D, G, DUAL>(a, b, kvh, pos, lane, t);
     if (blockIdx.x == 0 && pos < a.max_seq && wid == 0 && lane < LPR) {
         *reinterpret_cast<uint4*>(a.kcache + head_off + (size_t)pos * D + sub * 8) = t.kbits;
         *reinterpret_cast<uint4*>(a.vcache + head_off + (size_t)pos * D + sub * 8) = t.vbits;
@@ -771,9 +775,9 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a, unsigned lo
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc = fmaf(wf[j], xf[j], acc);
         acc = group_sum<LPW>(acc);
-        if (lr == 0) st_sc1_f(outp + row, acc);
+        if (lr == 0) st_act(outp + row, acc, DUAL);
     }
-    dep_signal(a.dep);
+    if constexpr (DUAL) dep_signal(a.dep);
     tls.end();
 }
 
@@ -1020,7 +1024,7 @@ struct Engine {
     // dual-chain step (engine_common.cuh): arrival counters [4 L][DEP_SHARDS x DEP_STRIDE], the epoch word, the error word,
     // and the second capture branch
     unsigned *dep_cnt = nullptr, *dep_epoch = nullptr, *dep_err = nullptr;
-    bool dual_ok = false;           // shapes suit it and PGK_DUAL_CHAIN != 0
+    bool dual_ok = false;           // PGK_DUAL_CHAIN=1 and the shapes suit it (opt-in: measured no faster)
     hipStream_t st2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t kv_bytes = 0, ws_bytes = 0;
@@ -1053,11 +1057,15 @@ static thread_local int g_last_grid = 0;     // workgroups of the most recent fu
 
 template <class WT, class XT, int M, int R, int PRO, int EPI, int C>
 static pgk_status launch_fused_c(const FusedArgs& a, int n_out, hipStream_t st, int force_grid) {
-    PGK_REQUIRE(C > 0 || (a.dep.wait_cnt == nullptr && a.dep.sig_cnt == nullptr), "engine: dual-chain step on a run-time-K GEMV (K=%d)", a.K);
     constexpr int OUT_PER_TRIP = (EPI == EPI_SWIGLU) ? R / 2 : R;
     const size_t lds = (size_t)M * a.K * sizeof(XT);
     PGK_REQUIRE(lds <= 156 * 1024, "engine: %d activation rows of K=%d do not fit LDS", M, a.K);
-    auto kfn = &fused_gemv_kernel<WT, XT, M, R, PRO, EPI, C>;
+    auto kfn = &fused_gemv_kernel<WT, XT, M, R, PRO, EPI, C, false>;
+    constexpr bool DUAL_OK = C > 0 && M == 1 && std::is_same<WT, bf16>::value && std::is_same<XT, float>::value && EPI != EPI_LOGITS && PRO != PRO_ATTN;
+    if (a.dep.sig_cnt || a.dep.wait_cnt) {
+        if constexpr (DUAL_OK) kfn = &fused_gemv_kernel<WT, XT, M, R, PRO, EPI, C, true>;
+        else return set_error(PGK_ERR_UNSUPPORTED, "engine: no dual-chain instance of this GEMV (M=%d, K=%d)", M, a.K);
+    }
     static bool attr_done = false;
     if (lds > 48 * 1024 && !attr_done) {
         PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
@@ -1140,7 +1148,8 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
     hipError_t he = hipSuccess;
 #define PGK_ATTN(GG)                                                               \
     case GG:                                                                       \
-        if (fused) he = launch_k(attn_oproj_kernel<D, GG>, grid, dim3(256), 0, st, a);              \
+        if (fused && a.dep.sig_cnt) he = launch_k(attn_oproj_kernel<D, GG, true>, grid, dim3(256), 0, st, a);   \
+        else if (fused) he = launch_k(attn_oproj_kernel<D, GG, false>, grid, dim3(256), 0, st, a);  \
         else if (direct) he = launch_k(attn_decode_kernel<D, GG, true>, grid, dim3(256), 0, st, a); \
         else he = launch_k(attn_decode_kernel<D, GG, false>, grid, dim3(256), 0, st, a);            \
         break;
@@ -1245,7 +1254,10 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
             if (fused) {
                 a.part = e->opart + (size_t)b0 * c.num_kv_heads * H; a.nsplit = c.num_kv_heads; a.h_out = h2;
                 a.dep = wire();
-                if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM_SUM, EPI_SWIGLU>(a, I, sA)) return r;
+                // dual chain: 4 rows per wave (half the workgroups, same per-row arithmetic) so that this kernel, spinning on
+                // every CU, still leaves the 256-register slots the attention kernel's workgroups need
+                if (dual) { if (pgk_status r = launch_fused<WT, XT, M, 4, PRO_NORM_SUM, EPI_SWIGLU>(a, I, sA)) return r; }
+                else if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM_SUM, EPI_SWIGLU>(a, I, sA)) return r;
                 launched();
                 mlp_in = h2;
                 done_gateup = true;
@@ -1385,7 +1397,7 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
 template <class WT>
 static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* launches, hipStream_t st2) {
     int b0 = 0;
-    const bool dual = e->dual_ok && batch <= 2;      // one chunk of one or two sequences on the fused path
+    const bool dual = e->dual_ok && batch == 1;      // one sequence on the fused path
     while (b0 < batch) {
         const int rem = batch - b0;
         pgk_status r;
@@ -1396,7 +1408,7 @@ static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* la
         if (mfma_ok) { const int m = rem > e->batched_max ? e->batched_max : rem; r = decode_chunk_batched<WT>(e, b0, m, rem == m, st, launches); b0 += m; }
         else if (rem >= 8) { r = decode_chunk<WT, bf16, 8>(e, b0, rem == 8, st, launches); b0 += 8; }
         else if (rem >= 4) { r = decode_chunk<WT, bf16, 4>(e, b0, rem == 4, st, launches); b0 += 4; }
-        else if (rem >= 2) { r = decode_chunk<WT, float, 2>(e, b0, rem == 2, st, launches, dual && batch == 2, st2); b0 += 2; }
+        else if (rem >= 2) { r = decode_chunk<WT, float, 2>(e, b0, rem == 2, st, launches); b0 += 2; }
         else { r = decode_chunk<WT, float, 1>(e, b0, true, st, launches, dual && batch == 1, st2); b0 += 1; }
         if (r != PGK_OK) return r;
     }
@@ -1524,10 +1536,10 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         // knows how to wait): K = 512 C with C in {1,2,3,4,6} and C x rows-per-wave <= 8
         auto c_ok = [](int K, int R) { const int cc = K / 512; return K % 512 == 0 && (cc == 1 || cc == 2 || cc == 3 || cc == 4 || cc == 6) && cc * R <= 8; };
         const int nq = e->qkv_dim();
-        const int r_qkv = nq >= 4096 ? 4 : (nq >= 2048 ? 2 : 1), r_gu = c.intermediate_size >= 4096 ? 4 : 2;
+        const int r_qkv = nq >= 4096 ? 4 : (nq >= 2048 ? 2 : 1), r_gu = 4;
         const int r_dn = c.hidden_size >= 4096 ? 4 : (c.hidden_size >= 2048 ? 2 : 1);
         const char* ed = getenv("PGK_DUAL_CHAIN");
-        e->dual_ok = !(ed && atoi(ed) == 0) && e->fused_attn && c.weight_format == 0 && c_ok(c.hidden_size, r_qkv) && c_ok(c.hidden_size, r_gu) &&
+        e->dual_ok = (ed && atoi(ed) == 1) && e->fused_attn && c.weight_format == 0 && c_ok(c.hidden_size, r_qkv) && c_ok(c.hidden_size, r_gu) &&
                      c_ok(c.intermediate_size, r_dn);
         if (e->dual_ok && r == PGK_OK) {
             if (hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -1968,6 +1980,26 @@ pgk_status pgk_engine_set_sampling(pgk_engine eh, float temperature, int top_k, 
     e->sample_temperature = temperature;
     e->sample_top_k = top_k;
     e->sample_top_p = top_p;
+    return PGK_OK;
+}
+
+// Diagnostic: dual-chain state after a device sync: h_out[0] = epoch, [1] = error word, [2 + k] = arrivals of layer kernel k
+// (k < 4 L, summed over the shards).
+pgk_status pgk_engine_dep_state(pgk_engine eh, uint32_t* h_out, int n) {
+    PGK_REQUIRE(eh && h_out, "pgk_engine_dep_state: null argument");
+    Engine* e = (Engine*)eh;
+    const int nk = 4 * e->cfg.num_layers;
+    PGK_REQUIRE(n >= nk + 2, "pgk_engine_dep_state: need %d words", nk + 2);
+    std::vector<uint32_t> host((size_t)nk * DEP_SHARDS * DEP_STRIDE + 2 * DEP_STRIDE);
+    PGK_CHECK_HIP(hipDeviceSynchronize());
+    PGK_CHECK_HIP(hipMemcpy(host.data(), e->dep_cnt, host.size() * 4, hipMemcpyDeviceToHost));
+    h_out[0] = host[(size_t)nk * DEP_SHARDS * DEP_STRIDE];
+    h_out[1] = host[(size_t)nk * DEP_SHARDS * DEP_STRIDE + DEP_STRIDE];
+    for (int k = 0; k < nk; ++k) {
+        uint32_t sum = 0;
+        for (int sh = 0; sh < DEP_SHARDS; ++sh) sum += host[((size_t)k * DEP_SHARDS + sh) * DEP_STRIDE];
+        h_out[2 + k] = sum;
+    }
     return PGK_OK;
 }
 

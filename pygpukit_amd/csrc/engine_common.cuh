@@ -133,6 +133,14 @@ __device__ __forceinline__ float4 ld_sc1_f4(const float* base, unsigned byte_off
     const dep_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);   // aux 16 = sc1
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+// activation accessors: write-through / L1-bypassing only when the step is wired as a dual chain (`coh`); the ordinary
+// single-stream step keeps ordinary loads and stores (an sc1 store drops its line from L2, so the next kernel's loads
+// would go to the fabric for nothing)
+__device__ __forceinline__ float ld_act(const float* p, bool coh) { return coh ? ld_sc1_f(p) : *p; }
+__device__ __forceinline__ void st_act(float* p, float v, bool coh) { if (coh) st_sc1_f(p, v); else *p = v; }
+__device__ __forceinline__ float4 ld_act4(const float* base, unsigned elem_off, bool coh) {
+    return coh ? ld_sc1_f4(base, elem_off * 4u) : *reinterpret_cast<const float4*>(base + elem_off);
+}
 __device__ __forceinline__ void dep_wait(const DepArgs& d) {
     if (d.wait_cnt) {
         if (threadIdx.x < 64) {

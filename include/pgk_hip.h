@@ -112,11 +112,14 @@ pgk_status pgk_event_create(pgk_event* out);
 pgk_status pgk_event_destroy(pgk_event e);
 pgk_status pgk_event_record(pgk_event e, pgk_stream s);
 pgk_status pgk_event_sync(pgk_event e);
+/* cudaStreamWaitEvent: work queued on `s` (NULL: the current stream) after this call runs after `e` */
+pgk_status pgk_stream_wait_event(pgk_stream s, pgk_event e);
 pgk_status pgk_event_query(pgk_event e, int* done);
 pgk_status pgk_event_elapsed_ms(pgk_event start, pgk_event stop, float* ms);
 /* CudaGraph native/core/cuda_graph.hpp:31-88: begin_capture / end_capture / replay /
  * synchronize / reset / is_ready / num_nodes.  Capture is on `stream` (thread-local
- * capture in the reference, cuda_graph.cu:84-107). */
+ * capture in the reference, cuda_graph.cu:84-107).  Pool blocks allocated by the capturing thread between begin and end
+ * are baked into the graph: freeing one only parks it until pgk_graph_destroy, so replays never find them recycled. */
 pgk_status pgk_graph_begin_capture(pgk_stream s);
 pgk_status pgk_graph_end_capture(pgk_stream s, pgk_graph* out);
 pgk_status pgk_graph_launch(pgk_graph g, pgk_stream s);
@@ -410,8 +413,10 @@ pgk_status pgk_engine_reset_log(pgk_engine e, pgk_stream s);
 /* In-graph stochastic sampling (the graph-compatible sample_topk_to_buf_ptr of src/pygpukit/ops/sampling.py:40-71, for the
  * whole-step graph): each step draws one token per sequence from the step's fp32 logits with pgk_sample_token's
  * semantics; the uniform numbers are row (step counter % n_rows) of `h_uniforms` [n_rows][max_batch], copied to the device
- * here.  temperature <= 0 restores greedy argmax.  Set before pgk_engine_capture; call again (same n_rows or fewer) to
- * queue fresh uniforms between replays; temperature / top_k / top_p changes need a re-capture. */
+ * here.  temperature <= 0 restores greedy argmax.  The sampling node's arguments are baked into a captured graph, so a
+ * call that changes on/off, temperature, top_k, top_p or n_rows (or has to grow a buffer) DROPS the engine's captured
+ * graph: pgk_engine_replay fails until pgk_engine_capture is called again.  A refill with identical parameters and
+ * n_rows keeps the graph and only queues fresh uniforms. */
 pgk_status pgk_engine_set_sampling(pgk_engine e, float temperature, int top_k, float top_p, const float* h_uniforms, int n_rows,
                                    pgk_stream s);
 /* Diagnostic: per logged step, {s_memtime (shader clock ticks), s_memrealtime (100 MHz ticks)} stamped by the

@@ -60,7 +60,7 @@ _PROTOS = {
     "pgk_stream_create": [c_void_pp, _I], "pgk_stream_destroy": [_V], "pgk_stream_sync": [_V],
     "pgk_stream_set_current": [_V], "pgk_stream_get_current": [c_void_pp],
     "pgk_event_create": [c_void_pp], "pgk_event_destroy": [_V], "pgk_event_record": [_V, _V],
-    "pgk_event_sync": [_V], "pgk_event_query": [_V, C.POINTER(_I)], "pgk_event_elapsed_ms": [_V, _V, C.POINTER(_F)],
+    "pgk_event_sync": [_V], "pgk_stream_wait_event": [_V, _V], "pgk_event_query": [_V, C.POINTER(_I)], "pgk_event_elapsed_ms": [_V, _V, C.POINTER(_F)],
     "pgk_graph_begin_capture": [_V], "pgk_graph_end_capture": [_V, c_void_pp], "pgk_graph_launch": [_V, _V],
     "pgk_graph_num_nodes": [_V, C.POINTER(_Z)], "pgk_graph_destroy": [_V], "pgk_stream_is_capturing": [_V, C.POINTER(_I)],
     "pgk_binary": [_V, _V, _V, _Z, _I, _I, _V], "pgk_binary_inplace": [_V, _V, _Z, _I, _I, _V],

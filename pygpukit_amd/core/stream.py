@@ -198,6 +198,7 @@ class CudaGraph:
         self._stream = Stream()
         self._g = 0
         self._capturing = False
+        self._order_ev = None
 
     def begin_capture(self) -> None:
         if self._capturing:
@@ -219,9 +220,25 @@ class CudaGraph:
         self._g = g.value
 
     def replay(self) -> None:
+        """Launch on the graph's private stream, ordered on both sides with the calling thread's current stream: work
+        already queued there (the inputs the graph reads) finishes first, and work queued there afterwards sees the
+        graph's results - the stream-ordered behaviour a launch on the current stream itself would have."""
         if not self._g:
             raise RuntimeError("CudaGraph: nothing captured")
-        _hip.call("pgk_graph_launch", C.c_void_p(self._g), C.c_void_p(self._stream.handle))
+        cur = C.c_void_p()
+        _hip.call("pgk_stream_get_current", C.byref(cur))
+        gs = C.c_void_p(self._stream.handle)
+        if cur.value != self._stream.handle:
+            if self._order_ev is None:
+                ev = C.c_void_p()
+                _hip.call("pgk_event_create", C.byref(ev))
+                self._order_ev = ev.value
+            _hip.call("pgk_event_record", C.c_void_p(self._order_ev), cur)
+            _hip.call("pgk_stream_wait_event", gs, C.c_void_p(self._order_ev))
+        _hip.call("pgk_graph_launch", C.c_void_p(self._g), gs)
+        if cur.value != self._stream.handle:
+            _hip.call("pgk_event_record", C.c_void_p(self._order_ev), gs)
+            _hip.call("pgk_stream_wait_event", cur, C.c_void_p(self._order_ev))
 
     def synchronize(self) -> None:
         self._stream.synchronize()
@@ -251,6 +268,9 @@ class CudaGraph:
     def __del__(self):
         try:
             self.reset()
+            if self._order_ev:
+                _hip.call("pgk_event_destroy", C.c_void_p(self._order_ev))
+                self._order_ev = None
         except Exception:
             pass
 

@@ -999,7 +999,7 @@ struct Engine {
     bool attn_direct_ok = false;
     // in-graph stochastic sampling (pgk_engine_set_sampling): temperature <= 0 keeps greedy argmax
     float sample_temperature = 0.f, sample_top_p = 1.f;
-    int sample_top_k = 0, u_cap = 0;
+    int sample_top_k = 0, u_cap = 0, u_alloc_rows = 0;   // u_cap: rows in use (ring length); u_alloc_rows: rows allocated
     float* u_ring = nullptr;       // [u_cap][max_batch] uniforms, row = step counter % u_cap
     void* sample_scratch = nullptr;   // top-k candidate keys (ops_sampling.hip), sized for max_batch rows
     size_t sample_scratch_cap = 0;
@@ -1940,33 +1940,45 @@ pgk_status pgk_engine_read_clock(pgk_engine eh, uint64_t* h_out, int n_steps, pg
 }
 
 // In-graph stochastic sampling.  temperature <= 0 restores greedy argmax.  `h_uniforms` [n_rows][max_batch] floats in
-// [0,1) are copied into the device ring (row r serves step counter r, modulo n_rows): queue as many rows as steps will be
-// replayed before the next call.  Must be set BEFORE pgk_engine_capture (it adds a node per chunk) and may be called
-// again afterwards with the same on/off state to refresh the uniforms or change temperature / top-k / top-p?  No:
-// those three are kernel arguments baked into the captured graph - re-capture after changing them.
+// [0,1) are copied into the device ring: step s of the log uses row s % n_rows.  The sampling node and its arguments
+// (ring pointer and length, scratch pointer, temperature, top-k, top-p) are baked into a captured graph, so ANY change
+// of them - switching sampling on or off, another temperature / top-k / top-p, another n_rows, a scratch buffer that had
+// to grow - drops the engine's captured graph: pgk_engine_replay then fails with "no captured graph" until
+// pgk_engine_capture is called again.  A refill with the same n_rows and the same parameters only overwrites the ring's
+// contents and keeps the graph.
 pgk_status pgk_engine_set_sampling(pgk_engine eh, float temperature, int top_k, float top_p, const float* h_uniforms, int n_rows,
                                    pgk_stream s) {
     PGK_REQUIRE(eh, "pgk_engine_set_sampling: null engine");
     Engine* e = (Engine*)eh;
     hipStream_t st = resolve_stream(s);
+    auto drop_graph = [&]() {
+        if (e->exec) { (void)hipStreamSynchronize(st); (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
+        if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+        e->graph_batch = 0;
+    };
     if (temperature <= 0.f) {
+        if (e->sample_temperature > 0.f) drop_graph();          // a captured sampling node must not be replayed as "greedy"
         e->sample_temperature = 0.f;
         return PGK_OK;
     }
     PGK_REQUIRE(top_k >= 0 && top_p > 0.f && top_p <= 1.f, "pgk_engine_set_sampling: need top_k >= 0 and 0 < top_p <= 1");
     PGK_REQUIRE(h_uniforms && n_rows >= 1, "pgk_engine_set_sampling: uniforms missing");
     const int B = e->cfg.max_batch;
-    if (n_rows > e->u_cap) {
+    bool changed = e->sample_temperature != temperature || e->sample_top_k != top_k || e->sample_top_p != top_p || n_rows != e->u_cap;
+    if (n_rows > e->u_alloc_rows) {
+        drop_graph();                                           // its nodes hold the old ring pointer
         PGK_CHECK_HIP(hipStreamSynchronize(st));
         if (e->u_ring) pgk_free(e->u_ring);
         e->u_ring = nullptr;
+        e->u_alloc_rows = 0;
         if (pgk_status r = pgk_malloc((void**)&e->u_ring, (size_t)n_rows * B * 4)) return r;
-        e->u_cap = n_rows;
+        e->u_alloc_rows = n_rows;
     }
     if (!e->sampled) {
         if (pgk_status r = pgk_malloc((void**)&e->sampled, (size_t)B * 4)) return r;
     }
     if (const size_t need = sample_scratch_bytes(B, e->cfg.vocab_size, top_k, top_p); need > e->sample_scratch_cap) {
+        drop_graph();
         PGK_CHECK_HIP(hipStreamSynchronize(st));
         if (e->sample_scratch) pgk_free(e->sample_scratch);
         e->sample_scratch = nullptr;
@@ -1974,9 +1986,10 @@ pgk_status pgk_engine_set_sampling(pgk_engine eh, float temperature, int top_k, 
         if (pgk_status r = pgk_malloc(&e->sample_scratch, need)) return r;
         e->sample_scratch_cap = need;
     }
-    // a shorter refill keeps the ring size (the graph holds u_cap): rows beyond n_rows keep their previous values
+    if (changed) drop_graph();
     PGK_CHECK_HIP(hipMemcpyAsync(e->u_ring, h_uniforms, (size_t)n_rows * B * 4, hipMemcpyHostToDevice, st));
     PGK_CHECK_HIP(hipStreamSynchronize(st));
+    e->u_cap = n_rows;                                          // ring length = rows queued: row index is step % n_rows
     e->sample_temperature = temperature;
     e->sample_top_k = top_k;
     e->sample_top_p = top_p;

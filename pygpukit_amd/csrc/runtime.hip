@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -54,16 +55,32 @@ hipStream_t resolve_stream(pgk_stream s) {
 
 // ------------------------------------------------------------------------------------------
 // Pooled allocator.  Size classes: powers of two from 512 B to 1 MiB, then multiples of 2 MiB.
-// Freed blocks go to a per-(device,class) free list; a hit costs no driver call, which also
-// makes allocation legal while a stream is being captured into a graph.
+// A hit costs no driver call, which also makes allocation legal while a stream is being captured.
+//
+// Every op is asynchronous, so a freed block may still be in use by work already queued.  The pool is therefore stream-
+// aware (the caching-allocator scheme): a block belongs to the stream that was current when it was allocated; a free puts
+// it on THAT stream's list, where the same stream may reuse it at once (stream order protects it); another stream takes
+// it only when the owning stream has drained (hipStreamQuery), i.e. when everything queued before the free has finished.
+// Blocks allocated while a graph is being captured (pgk_graph_begin_capture .. end_capture on this thread) are baked into
+// the graph's nodes: freeing one parks it until that graph is destroyed, so no replay can find its temporaries recycled.
+// (A block used on a stream other than its owner's is the caller's to order - an event or a sync before dropping it.)
 // ------------------------------------------------------------------------------------------
+struct Block {
+    int dev;
+    size_t cls;
+    hipStream_t stream;      // owner
+    uint64_t capture_id;     // != 0: allocated during that capture
+};
 struct Pool {
     std::mutex mu;
-    std::map<std::pair<int, size_t>, std::vector<void*>> free_lists;
-    std::unordered_map<void*, std::pair<int, size_t>> live;  // ptr -> (device, class bytes)
+    std::map<std::tuple<int, size_t, hipStream_t>, std::vector<void*>> free_lists;
+    std::unordered_map<void*, Block> live;
+    std::map<uint64_t, std::vector<std::pair<void*, Block>>> parked;   // capture id -> freed blocks the graph may still write
+    uint64_t next_capture_id = 1;
     pgk_pool_stats_t st{};
     size_t reserved = 0;
 };
+static thread_local uint64_t g_capture_id = 0;   // the capture this thread is recording (0: none)
 static Pool& pool() {
     static Pool* p = new Pool();  // intentionally leaked: frees may run during interpreter teardown
     return *p;
@@ -142,20 +159,34 @@ pgk_status pgk_malloc(void** ptr, size_t nbytes) {
     int dev = 0;
     PGK_CHECK_HIP(hipGetDevice(&dev));
     const size_t cls = size_class(nbytes ? nbytes : 1);
+    hipStream_t owner = resolve_stream(nullptr);
     Pool& P = pool();
     {
         std::lock_guard<std::mutex> lk(P.mu);
         P.st.n_alloc++;
-        auto it = P.free_lists.find({dev, cls});
-        if (it != P.free_lists.end() && !it->second.empty()) {
-            void* p = it->second.back();
-            it->second.pop_back();
-            P.live[p] = {dev, cls};
+        auto take = [&](std::vector<void*>& list) {
+            void* p = list.back();
+            list.pop_back();
+            P.live[p] = Block{dev, cls, owner, g_capture_id};
             P.st.n_pool_hit++;
             P.st.bytes_cached -= cls;
             P.st.bytes_in_use += cls;
             *ptr = p;
-            return PGK_OK;
+        };
+        auto it = P.free_lists.find({dev, cls, owner});
+        if (it != P.free_lists.end() && !it->second.empty()) { take(it->second); return PGK_OK; }
+        // another stream's cached block of this class: only once that stream has drained (never while capturing: a
+        // query on a capturing stream is an error, and the answer would say nothing about replays)
+        if (g_capture_id == 0) {
+            for (auto lo = P.free_lists.lower_bound({dev, cls, nullptr}); lo != P.free_lists.end(); ++lo) {
+                if (std::get<0>(lo->first) != dev || std::get<1>(lo->first) != cls) break;
+                if (lo->second.empty()) continue;
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(std::get<2>(lo->first), &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); continue; }
+                const hipError_t q = hipStreamQuery(std::get<2>(lo->first));
+                if (q == hipSuccess) { take(lo->second); return PGK_OK; }
+                (void)hipGetLastError();
+            }
         }
     }
     void* p = nullptr;
@@ -169,7 +200,7 @@ pgk_status pgk_malloc(void** ptr, size_t nbytes) {
     if (e != hipSuccess)
         return set_error(PGK_ERR_HIP, "pgk_malloc(%zu bytes): %s", nbytes, hipGetErrorString(e));
     std::lock_guard<std::mutex> lk(P.mu);
-    P.live[p] = {dev, cls};
+    P.live[p] = Block{dev, cls, owner, g_capture_id};
     P.st.n_device_malloc++;
     P.st.bytes_in_use += cls;
     P.reserved += cls;
@@ -184,12 +215,14 @@ pgk_status pgk_free(void* ptr) {
     std::lock_guard<std::mutex> lk(P.mu);
     auto it = P.live.find(ptr);
     PGK_REQUIRE(it != P.live.end(), "pgk_free: pointer %p was not allocated by pgk_malloc", ptr);
-    const auto key = it->second;
+    const Block b = it->second;
     P.live.erase(it);
-    P.free_lists[key].push_back(ptr);
     P.st.n_free++;
-    P.st.bytes_in_use -= key.second;
-    P.st.bytes_cached += key.second;
+    P.st.bytes_in_use -= b.cls;
+    P.st.bytes_cached += b.cls;
+    auto pk = b.capture_id ? P.parked.find(b.capture_id) : P.parked.end();
+    if (pk != P.parked.end()) pk->second.push_back({ptr, b});                    // the graph that captured it is still alive
+    else P.free_lists[{b.dev, b.cls, b.stream}].push_back(ptr);
     return PGK_OK;
 }
 
@@ -208,9 +241,9 @@ pgk_status pgk_pool_trim(void) {
         std::lock_guard<std::mutex> lk(P.mu);
         for (auto& kv : P.free_lists) {
             for (void* p : kv.second) {
-                victims.push_back({kv.first.first, p});
-                P.st.bytes_cached -= kv.first.second;
-                P.reserved -= kv.first.second;
+                victims.push_back({std::get<0>(kv.first), p});
+                P.st.bytes_cached -= std::get<1>(kv.first);
+                P.reserved -= std::get<1>(kv.first);
             }
             kv.second.clear();
         }
@@ -338,6 +371,12 @@ pgk_status pgk_event_record(pgk_event e, pgk_stream s) {
     PGK_CHECK_HIP(hipEventRecord((hipEvent_t)e, resolve_stream(s)));
     return PGK_OK;
 }
+// queue a wait for `e` on stream `s` (NULL: the current stream): everything enqueued on s afterwards runs after e
+pgk_status pgk_stream_wait_event(pgk_stream s, pgk_event e) {
+    PGK_REQUIRE(e, "pgk_stream_wait_event: null event");
+    PGK_CHECK_HIP(hipStreamWaitEvent(resolve_stream(s), (hipEvent_t)e, 0));
+    return PGK_OK;
+}
 pgk_status pgk_event_sync(pgk_event e) { PGK_CHECK_HIP(hipEventSynchronize((hipEvent_t)e)); return PGK_OK; }
 pgk_status pgk_event_query(pgk_event e, int* done) {
     PGK_REQUIRE(done, "pgk_event_query: null output");
@@ -355,23 +394,44 @@ pgk_status pgk_event_elapsed_ms(pgk_event start, pgk_event stop, float* ms) {
 struct GraphObj {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    uint64_t capture_id = 0;     // pool blocks allocated during the capture stay parked while this object lives
 };
 
+// give the blocks a destroyed (or failed) capture was holding back to their owners' lists
+static void release_capture(uint64_t id) {
+    if (!id) return;
+    Pool& P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    auto it = P.parked.find(id);
+    if (it == P.parked.end()) return;
+    for (auto& pb : it->second) P.free_lists[{pb.second.dev, pb.second.cls, pb.second.stream}].push_back(pb.first);
+    P.parked.erase(it);
+}
+
 pgk_status pgk_graph_begin_capture(pgk_stream s) {
+    PGK_REQUIRE(g_capture_id == 0, "pgk_graph_begin_capture: this thread is already capturing");
     PGK_CHECK_HIP(hipStreamBeginCapture(resolve_stream(s), hipStreamCaptureModeRelaxed));
+    Pool& P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    g_capture_id = P.next_capture_id++;
+    P.parked[g_capture_id];      // exists <=> the capture / its graph is alive
     return PGK_OK;
 }
 pgk_status pgk_graph_end_capture(pgk_stream s, pgk_graph* out) {
     PGK_REQUIRE(out, "pgk_graph_end_capture: null output");
     GraphObj* g = new GraphObj();
+    g->capture_id = g_capture_id;
+    g_capture_id = 0;
     hipError_t e = hipStreamEndCapture(resolve_stream(s), &g->graph);
     if (e != hipSuccess || !g->graph) {
+        release_capture(g->capture_id);
         delete g;
         return set_error(PGK_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
     }
     e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
     if (e != hipSuccess) {
         (void)hipGraphDestroy(g->graph);
+        release_capture(g->capture_id);
         delete g;
         return set_error(PGK_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
     }
@@ -393,6 +453,7 @@ pgk_status pgk_graph_destroy(pgk_graph g) {
     GraphObj* o = (GraphObj*)g;
     if (o->exec) (void)hipGraphExecDestroy(o->exec);
     if (o->graph) (void)hipGraphDestroy(o->graph);
+    release_capture(o->capture_id);
     delete o;
     return PGK_OK;
 }

@@ -36,6 +36,12 @@ struct StFile {
     std::map<std::string, size_t> index;
 };
 
+// bytes per element for the Dtype ids below
+size_t dtype_bytes(int id) {
+    static const size_t b[12] = {4, 2, 2, 8, 1, 1, 4, 8, 2, 1, 1, 1};
+    return id >= 0 && id < 12 ? b[id] : 0;
+}
+
 int dtype_id(const std::string& s) {
     static const std::map<std::string, int> m = {{"F32", 0}, {"F16", 1}, {"BF16", 2}, {"F64", 3}, {"F8_E4M3", 4}, {"F8_E5M2", 5},
                                                   {"I32", 6}, {"I64", 7}, {"I16", 8}, {"I8", 9}, {"U8", 10}, {"BOOL", 11}};
@@ -73,14 +79,18 @@ struct Json {
         ++p;
         return out;
     }
+    // non-negative integer below 2^62 (shape dimensions, byte offsets): a sign, a fraction, an exponent or more digits
+    // than that fail the parse - the header comes from an untrusted file
     int64_t num() {
         ws();
-        bool neg = false;
-        if (p < e && *p == '-') { neg = true; ++p; }
         if (p >= e || *p < '0' || *p > '9') { fail = true; return 0; }
         int64_t v = 0;
-        while (p < e && *p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
-        return neg ? -v : v;
+        while (p < e && *p >= '0' && *p <= '9') {
+            if (v > ((int64_t)1 << 62) / 10 - 1) { fail = true; return 0; }
+            v = v * 10 + (*p++ - '0');
+        }
+        if (p < e && (*p == '.' || *p == 'e' || *p == 'E')) { fail = true; return 0; }
+        return v;
     }
     void skip_value() {   // any JSON value (used for __metadata__ and unknown keys)
         ws();
@@ -170,8 +180,19 @@ pgk_status pgk_st_open(const char* path, void** handle) {
             } while (j.eat(','));
             if (!j.eat('}')) return bail("malformed header (tensor entry end)");
             if (t.dtype < 0) return bail("unknown dtype string");
-            if (t.end < t.begin || f->data_start + t.end > f->size) return bail("tensor data outside the file");
+            // subtraction form: no sum that could wrap (the reference's Rust reader rejects the same inputs)
+            if (t.end < t.begin || t.end > f->size - f->data_start) return bail("tensor data outside the file");
             if (t.shape.size() > 8) return bail("tensor rank above 8");
+            {
+                uint64_t elems = 1;
+                for (int64_t d : t.shape) {
+                    if (d < 0) return bail("negative dimension");
+                    if (d != 0 && elems > (uint64_t)f->size / (uint64_t)d + 1) { elems = ~0ull; break; }   // already larger than the file
+                    elems *= (uint64_t)d;
+                }
+                if (elems == ~0ull || elems > (uint64_t)f->size || elems * dtype_bytes(t.dtype) != t.end - t.begin)
+                    return bail("shape x dtype size does not match data_offsets");
+            }
             f->index[t.name] = f->tensors.size();
             f->tensors.push_back(std::move(t));
         } while (j.eat(','));

@@ -90,7 +90,14 @@ class Engine:
         """Switch the decode step from greedy argmax to a temperature / top-k / top-p draw made inside the step (and so
         inside a captured graph).  `uniforms` [n_steps, max_batch] float32 in [0,1) (drawn from `seed` when omitted) are
         queued on the device: step s uses row s % n_steps.  Returns the uniforms used (None when switching back to
-        greedy with temperature <= 0).  Call before capture(); call again to queue fresh uniforms."""
+        greedy with temperature <= 0).  Call before capture().  Calling again with the same parameters and the same
+        number of rows only queues fresh uniforms; any other change (on/off, temperature, top_k, top_p, row count)
+        drops the captured graph - capture() again before replay()."""
+        key = (0.0,) if temperature <= 0 else (float(temperature), int(top_k), float(top_p),
+                                                int(uniforms.shape[0]) if uniforms is not None else int(n_steps))
+        if key != getattr(self, "_sampling_key", (0.0,)):
+            self._captured_batch = 0
+        self._sampling_key = key
         if temperature <= 0:
             _hip.call("pgk_engine_set_sampling", self.handle, C.c_float(0.0), 0, C.c_float(1.0), None, 0, None)
             return None

@@ -65,6 +65,26 @@ def test_reader_rejects_bad_files(tmp_path):
     bad.write_bytes(len(hj).to_bytes(8, "little") + hj + b"\0")
     with pytest.raises(ValueError, match="unknown dtype"):
         ST.SafeTensorsFile(str(bad))
+    # a crafted header must not be able to point outside the mapping: negative or wrapping offsets, offsets past the file
+    # after the add, shapes that disagree with the byte range, negative / overflowing / fractional numbers
+    for entry, why in (
+            ('{"dtype": "U8", "shape": [1], "data_offsets": [0, -1]}', "malformed"),
+            ('{"dtype": "U8", "shape": [1], "data_offsets": [0, 18446744073709551615]}', "malformed"),
+            ('{"dtype": "U8", "shape": [1], "data_offsets": [0, 4611686018427387904]}', "malformed|outside the file"),
+            ('{"dtype": "U8", "shape": [16], "data_offsets": [8, 24]}', "outside the file"),
+            ('{"dtype": "F32", "shape": [1000, 1000], "data_offsets": [0, 16]}', "does not match"),
+            ('{"dtype": "F32", "shape": [4294967296, 4294967296], "data_offsets": [0, 16]}', "does not match"),
+            ('{"dtype": "F32", "shape": [-4], "data_offsets": [0, 16]}', "malformed"),
+            ('{"dtype": "F32", "shape": [4.0], "data_offsets": [0, 16]}', "malformed"),
+            ('{"dtype": "F32", "shape": [2], "data_offsets": [8, 4]}', "outside the file|does not match"),
+            ('{"dtype": "BF16", "shape": [3], "data_offsets": [0, 16]}', "does not match")):
+        hj = ('{"t": ' + entry + "}").encode()
+        bad.write_bytes(len(hj).to_bytes(8, "little") + hj + b"\0" * 16)
+        with pytest.raises(ValueError, match=why):
+            ST.SafeTensorsFile(str(bad))
+    hj = b'{"t": {"dtype": "F32", "shape": [0, 7], "data_offsets": [4, 4]}}'      # an empty tensor is legal
+    bad.write_bytes(len(hj).to_bytes(8, "little") + hj + b"\0" * 16)
+    assert ST.SafeTensorsFile(str(bad)).tensor_info("t").size_bytes == 0
 
 
 def test_sharded_index(tmp_path):

@@ -84,3 +84,82 @@ class TestStreamManagerOnDevice:
         np.testing.assert_array_equal(c1.to_numpy(), a + b)
         np.testing.assert_array_equal(c2.to_numpy(), a * b)
         pk.device_synchronize()
+
+
+@pytest.mark.gpu
+class TestPoolIsStreamAndGraphAware:
+    """The device pool hands a freed block back at once only to the stream that owns it; another stream gets it when the
+    owner has drained; blocks allocated while a graph is captured stay out of circulation until the graph is destroyed."""
+
+    def test_a_block_freed_under_pending_work_is_not_given_to_another_stream(self):
+        import pygpukit_amd as pk
+        from pygpukit_amd import ops
+        from pygpukit_amd.core import from_numpy, zeros
+
+        n = 3 * 1024 * 1024 + 17                      # an unusual size class (14 MiB of fp32): nobody else caches it
+        big = from_numpy(np.ones(64 * 1024 * 1024, np.float32))
+        sa, sb = Stream(), Stream()
+        with sa:
+            x = zeros((n,), "float32")
+            ptr = x.data_ptr()
+            for _ in range(40):                       # ~ms of queued work on sa
+                ops.add_inplace(big, big)
+            del x                                      # freed while sa is still busy
+            same_stream = zeros((n,), "float32")      # the owner may reuse it: stream order protects it
+            assert same_stream.data_ptr() == ptr
+            del same_stream
+        with sb:
+            other = zeros((n,), "float32")
+            assert other.data_ptr() != ptr            # sa has not drained: sb must not get the block
+            del other
+        sa.synchronize()
+        sb.synchronize()
+        with sb:
+            got = [zeros((n,), "float32") for _ in range(3)]
+            assert ptr in [g.data_ptr() for g in got]  # drained: now it may change hands
+        pk.device_synchronize()
+
+    def test_blocks_allocated_during_capture_are_pinned_until_the_graph_is_reset(self):
+        import pygpukit_amd as pk
+        from pygpukit_amd import ops
+        from pygpukit_amd.core import CudaGraph, from_numpy, zeros
+
+        n = 5 * 1024 * 1024 + 3
+        a = from_numpy(np.arange(n, dtype=np.float32))
+        out = zeros((n,), "float32")
+        g = CudaGraph()
+        g.begin_capture()
+        tmp = ops.add(a, a)                            # a temporary allocated INSIDE the capture
+        ptr = tmp.data_ptr()
+        ops.add(tmp, a, out=out)
+        del tmp                                        # freed right away - the graph's nodes still write and read it
+        g.end_capture()
+        held = [zeros((n,), "float32") for _ in range(6)]
+        assert ptr not in [h.data_ptr() for h in held]
+        for h in held:
+            ops.copy_to(a, h)                          # scribble over everything the pool hands out
+        g.replay()
+        g.synchronize()
+        np.testing.assert_array_equal(out.to_numpy(), 3 * np.arange(n, dtype=np.float32))
+        del held
+        g.reset()                                      # graph gone: the block returns to the pool
+        with Stream(g.get_stream_handle()):
+            again = [zeros((n,), "float32") for _ in range(8)]
+        assert ptr in [h.data_ptr() for h in again]
+
+    def test_replay_is_ordered_with_the_current_stream(self):
+        from pygpukit_amd import ops
+        from pygpukit_amd.core import CudaGraph, from_numpy, zeros
+
+        n = 1 << 22
+        x = zeros((n,), "float32")
+        y = zeros((n,), "float32")
+        g = CudaGraph()
+        g.begin_capture()
+        ops.add(x, x, out=y)
+        g.end_capture()
+        for k in range(1, 6):
+            src = from_numpy(np.full(n, float(k), np.float32))
+            ops.copy_to(src, x)                        # current (default) stream
+            g.replay()                                 # private stream: must see the copy ...
+            np.testing.assert_array_equal(y.to_numpy()[:: 65537], np.full(n, 2.0 * k, np.float32)[:: 65537])   # ... and the read must see the replay

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <tuple>
 #include <mutex>
 #include <string>
@@ -31,6 +32,8 @@ int set_error(int code, const char* fmt, ...) {
     return code;
 }
 
+static void register_stream(hipStream_t s);   // pool registry (below)
+
 // One library-owned (non-blocking) stream per device, created on first use.
 static std::mutex g_stream_mu;
 static hipStream_t g_default_streams[64] = {nullptr};
@@ -43,6 +46,7 @@ static hipStream_t default_stream() {
         hipStream_t s = nullptr;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
         g_default_streams[dev] = s;
+        register_stream(s);
     }
     return g_default_streams[dev];
 }
@@ -76,6 +80,7 @@ struct Pool {
     std::map<std::tuple<int, size_t, hipStream_t>, std::vector<void*>> free_lists;
     std::unordered_map<void*, Block> live;
     std::map<uint64_t, std::vector<std::pair<void*, Block>>> parked;   // capture id -> freed blocks the graph may still write
+    std::set<hipStream_t> streams;   // streams this library created and has not destroyed: the only ones it may query
     uint64_t next_capture_id = 1;
     pgk_pool_stats_t st{};
     size_t reserved = 0;
@@ -84,6 +89,12 @@ static thread_local uint64_t g_capture_id = 0;   // the capture this thread is r
 static Pool& pool() {
     static Pool* p = new Pool();  // intentionally leaked: frees may run during interpreter teardown
     return *p;
+}
+
+static void register_stream(hipStream_t s) {
+    Pool& P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.streams.insert(s);
 }
 
 static size_t size_class(size_t n) {
@@ -177,15 +188,20 @@ pgk_status pgk_malloc(void** ptr, size_t nbytes) {
         if (it != P.free_lists.end() && !it->second.empty()) { take(it->second); return PGK_OK; }
         // another stream's cached block of this class: only once that stream has drained (never while capturing: a
         // query on a capturing stream is an error, and the answer would say nothing about replays)
+        // key stream == nullptr: blocks whose owner was destroyed (after a sync) - free for anyone
         if (g_capture_id == 0) {
             for (auto lo = P.free_lists.lower_bound({dev, cls, nullptr}); lo != P.free_lists.end(); ++lo) {
                 if (std::get<0>(lo->first) != dev || std::get<1>(lo->first) != cls) break;
                 if (lo->second.empty()) continue;
-                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-                if (hipStreamIsCapturing(std::get<2>(lo->first), &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); continue; }
-                const hipError_t q = hipStreamQuery(std::get<2>(lo->first));
-                if (q == hipSuccess) { take(lo->second); return PGK_OK; }
-                (void)hipGetLastError();
+                hipStream_t os = std::get<2>(lo->first);
+                if (os != nullptr) {
+                    if (!P.streams.count(os)) continue;                     // not ours to query
+                    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                    if (hipStreamIsCapturing(os, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); continue; }
+                    if (hipStreamQuery(os) != hipSuccess) { (void)hipGetLastError(); continue; }
+                }
+                take(lo->second);
+                return PGK_OK;
             }
         }
     }
@@ -222,7 +238,7 @@ pgk_status pgk_free(void* ptr) {
     P.st.bytes_cached += b.cls;
     auto pk = b.capture_id ? P.parked.find(b.capture_id) : P.parked.end();
     if (pk != P.parked.end()) pk->second.push_back({ptr, b});                    // the graph that captured it is still alive
-    else P.free_lists[{b.dev, b.cls, b.stream}].push_back(ptr);
+    else P.free_lists[{b.dev, b.cls, P.streams.count(b.stream) ? b.stream : nullptr}].push_back(ptr);
     return PGK_OK;
 }
 
@@ -340,11 +356,42 @@ pgk_status pgk_stream_create(pgk_stream* out, int high_priority) {
     PGK_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     hipStream_t s = nullptr;
     PGK_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? hi : lo));
+    {
+        Pool& P = pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.streams.insert(s);
+    }
     *out = s;
     return PGK_OK;
 }
+// Drains the stream first: the pool blocks it owns (cached or still live) then belong to nobody and may be reused by anyone.
 pgk_status pgk_stream_destroy(pgk_stream s) {
-    if (s) PGK_CHECK_HIP(hipStreamDestroy((hipStream_t)s));
+    if (!s) return PGK_OK;
+    hipStream_t st = (hipStream_t)s;
+    bool ours = false;
+    {
+        Pool& P = pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        ours = P.streams.count(st) != 0;
+    }
+    if (!ours) return PGK_OK;             // a wrapped foreign handle: not ours to destroy (or already destroyed)
+    (void)hipStreamSynchronize(st);
+    {
+        Pool& P = pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.streams.erase(st);
+        for (auto it = P.free_lists.begin(); it != P.free_lists.end();) {
+            if (std::get<2>(it->first) == st) {
+                auto& orphan = P.free_lists[{std::get<0>(it->first), std::get<1>(it->first), nullptr}];
+                orphan.insert(orphan.end(), it->second.begin(), it->second.end());
+                it = P.free_lists.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+    if (g_has_current && g_current_stream == st) { g_current_stream = nullptr; g_has_current = false; }
+    PGK_CHECK_HIP(hipStreamDestroy(st));
     return PGK_OK;
 }
 pgk_status pgk_stream_sync(pgk_stream s) { PGK_CHECK_HIP(hipStreamSynchronize(resolve_stream(s))); return PGK_OK; }
@@ -404,7 +451,8 @@ static void release_capture(uint64_t id) {
     std::lock_guard<std::mutex> lk(P.mu);
     auto it = P.parked.find(id);
     if (it == P.parked.end()) return;
-    for (auto& pb : it->second) P.free_lists[{pb.second.dev, pb.second.cls, pb.second.stream}].push_back(pb.first);
+    for (auto& pb : it->second)
+        P.free_lists[{pb.second.dev, pb.second.cls, P.streams.count(pb.second.stream) ? pb.second.stream : nullptr}].push_back(pb.first);
     P.parked.erase(it);
 }
 

@@ -462,6 +462,9 @@ struct AttnArgs {
     float* opart;         // [B][Hkv][H]
     bf16* attn_direct16;  // whole-context variant: bf16 output instead of attn_direct (batched MFMA o_proj reads it)
     DepArgs dep;          // dual-chain step (attn_oproj_kernel only); all null otherwise
+    // GQA groups other than the instantiated 1 / 2 / 4 query heads per kv head run as several launches over head chunks:
+    // this launch serves query heads kvh * g_total + g_off + [0, G) of every kv head (ordinary launch: g_total = G, g_off = 0)
+    int g_total, g_off;
 };
 
 template <int D, int G>
@@ -483,7 +486,7 @@ __device__ __forceinline__ void prepare_new_token(const AttnArgs& a, int b, int 
 #pragma unroll
     for (int g = 0; g < G + 2; ++g) {
         // q/k/v come from the previous kernel of this step: sc1 loads (dual chain, engine_common.cuh)
-        const unsigned eoff = (g < G) ? (unsigned)(kvh * G + g) * D : (g == G ? (unsigned)(a.hq + kvh) * D : (unsigned)(a.hq + a.hkv + kvh) * D);
+        const unsigned eoff = (g < G) ? (unsigned)(kvh * a.g_total + a.g_off + g) * D : (g == G ? (unsigned)(a.hq + kvh) * D : (unsigned)(a.hq + a.hkv + kvh) * D);
         const float4 u = ld_act4(row, eoff + sub * 8, coh), v = ld_act4(row, eoff + sub * 8 + 4, coh);
         raw[g][0] = u.x; raw[g][1] = u.y; raw[g][2] = u.z; raw[g][3] = u.w;
         raw[g][4] = v.x; raw[g][5] = v.y; raw[g][6] = v.z; raw[g][7] = v.w;
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
         const int pos = a.positions[b];
         NewToken<D, G> t;
         prepare_new_token<D, G>(a, b, kvh, pos, lane, t);
-        if (pos < a.max_seq && wid == 0 && lane < LPR) {
+        if (pos < a.max_seq && wid == 0 && lane < LPR && a.g_off == 0) {
             *reinterpret_cast<uint4*>(a.kcache + head_off + (size_t)pos * D + sub * 8) = t.kbits;
             *reinterpret_cast<uint4*>(a.vcache + head_off + (size_t)pos * D + sub * 8) = t.vbits;
         }
@@ -586,9 +589,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
         if (pos < a.max_seq && wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
         decode_block_merge_lds<D, G>(st, lds, attn_out, lane, wid);
         if (a.attn_direct16) {
-            for (int e = threadIdx.x; e < G * D; e += 256) a.attn_direct16[((size_t)b * a.hq + (size_t)kvh * G) * D + e] = from_f<bf16>(attn_out[e]);
+            for (int e = threadIdx.x; e < G * D; e += 256) a.attn_direct16[((size_t)b * a.hq + (size_t)kvh * a.g_total + a.g_off) * D + e] = from_f<bf16>(attn_out[e]);
         } else {
-            for (int e = threadIdx.x; e < G * D; e += 256) a.attn_direct[((size_t)b * a.hq + (size_t)kvh * G) * D + e] = attn_out[e];
+            for (int e = threadIdx.x; e < G * D; e += 256) a.attn_direct[((size_t)b * a.hq + (size_t)kvh * a.g_total + a.g_off) * D + e] = attn_out[e];
         }
         tls.end();
         return;
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
     const int chunk = decode_chunk_len(ctx, a.nsplit, 4 * PPW);
     const int c0 = min((int)blockIdx.x * chunk, ctx), c1 = min(c0 + chunk, ctx);
     const bool owns_new = (pos < a.max_seq) && (pos >= c0) && (pos < c1);
-    if (owns_new && wid == 0 && lane < LPR) {
+    if (owns_new && wid == 0 && lane < LPR && a.g_off == 0) {
         *reinterpret_cast<uint4*>(a.kcache + head_off + (size_t)pos * D + sub * 8) = t.kbits;
         *reinterpret_cast<uint4*>(a.vcache + head_off + (size_t)pos * D + sub * 8) = t.vbits;
     }
@@ -611,9 +614,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
     if constexpr (DIRECT) {
         // this workgroup saw the whole context: normalise here and skip the merge launch
         decode_block_merge_lds<D, G>(st, lds, attn_out, lane, wid);
-        for (int e = threadIdx.x; e < G * D; e += 256) a.attn_direct[((size_t)b * a.hq + (size_t)kvh * G) * D + e] = attn_out[e];
+        for (int e = threadIdx.x; e < G * D; e += 256) a.attn_direct[((size_t)b * a.hq + (size_t)kvh * a.g_total + a.g_off) * D + e] = attn_out[e];
     } else {
-        decode_block_merge<D, G>(st, lds, a.part + (((size_t)b * a.hq + (size_t)kvh * G) * a.nsplit + blockIdx.x) * RS,
+        decode_block_merge<D, G>(st, lds, a.part + (((size_t)b * a.hq + (size_t)kvh * a.g_total + a.g_off) * a.nsplit + blockIdx.x) * RS,
                                  (size_t)a.nsplit * RS, lane, wid);
         if (a.merge_counter) {
             // In-launch merge (saves the merge kernel and its boundary): publish this slice's records, take a ticket,
@@ -1105,6 +1108,14 @@ static pgk_status launch_fused_auto(const FusedArgs& a, int n_out, hipStream_t s
     }
 }
 
+// attention launches per layer for a GQA group of G query heads per kv head (chunks of 4 / 2 / 1 beyond the instantiated sizes)
+static int gqa_chunks(int G) {
+    if (G == 1 || G == 2 || G == 4) return 1;
+    int n = 0;
+    for (int off = 0; off < G; ++n) off += (G - off >= 4) ? 4 : ((G - off >= 2) ? 2 : 1);
+    return n;
+}
+
 template <int D>
 static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, hipStream_t st, bool direct_bf16 = false,
                               const DepArgs* dep = nullptr) {
@@ -1146,6 +1157,22 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
     if (dep && fused) a.dep = *dep;
     g_last_grid = (int)(grid.x * grid.y * grid.z);
     hipError_t he = hipSuccess;
+    a.g_total = G;
+    a.g_off = 0;
+    if (G != 1 && G != 2 && G != 4) {
+        // any other group size (Qwen2.5-7B: 28 / 4 = 7): chunks of 4, 2 and 1 query heads per kv head, one launch each -
+        // every chunk re-reads the kv head's K/V rows, which is what the reference's GQA-expanded cache costs for ALL heads
+        PGK_REQUIRE(!fused && !inmerge, "engine: fused / in-launch-merge attention needs a GQA group of 1, 2 or 4");
+        for (int off = 0; off < G;) {
+            const int gc = (G - off >= 4) ? 4 : ((G - off >= 2) ? 2 : 1);
+            a.g_off = off;
+            if (gc == 4) he = direct ? launch_k(attn_decode_kernel<D, 4, true>, grid, dim3(256), 0, st, a) : launch_k(attn_decode_kernel<D, 4, false>, grid, dim3(256), 0, st, a);
+            else if (gc == 2) he = direct ? launch_k(attn_decode_kernel<D, 2, true>, grid, dim3(256), 0, st, a) : launch_k(attn_decode_kernel<D, 2, false>, grid, dim3(256), 0, st, a);
+            else he = direct ? launch_k(attn_decode_kernel<D, 1, true>, grid, dim3(256), 0, st, a) : launch_k(attn_decode_kernel<D, 1, false>, grid, dim3(256), 0, st, a);
+            PGK_CHECK_HIP(he);
+            off += gc;
+        }
+    } else {
 #define PGK_ATTN(GG)                                                               \
     case GG:                                                                       \
         if (fused && a.dep.sig_cnt) he = launch_k(attn_oproj_kernel<D, GG, true>, grid, dim3(256), 0, st, a);   \
@@ -1155,10 +1182,11 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
         break;
     switch (G) {
         PGK_ATTN(1) PGK_ATTN(2) PGK_ATTN(4)
-        default: return set_error(PGK_ERR_UNSUPPORTED, "engine: GQA group %d not in {1,2,4}", G);
+        default: break;
     }
 #undef PGK_ATTN
     PGK_CHECK_HIP(he);
+    }
     if (!fused && !direct && !inmerge) {
         PGK_CHECK_HIP(launch_k(attn_merge_kernel<D>, dim3(c.num_heads, m), dim3(D), 0, st, (const float*)a.part,
                                e->attnv + (size_t)b0 * c.num_heads * D, (int)c.num_heads, (int)a.nsplit));
@@ -1241,7 +1269,7 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
             a.res = h; a.out = h; a.ld_out = H;
             if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_PLAIN, EPI_RESID>(a, H, st)) return r;
             launched();
-            *launches += ((e->attn_direct_ok && M >= 3) || e->merge_cnt) ? 1 : 2;   // o_proj (+ the merge kernel unless attention normalised in place)
+            *launches += (((e->attn_direct_ok && M >= 3) || e->merge_cnt) ? 1 : 2) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;   // o_proj (+ the merge kernel unless attention normalised in place)
         }
         // 4. act = silu(Wg x) * (Wu x), x = rmsnorm(h [+ sum of o_proj partials])
         mark(KC_GATEUP);
@@ -1364,7 +1392,7 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
         a.xin16 = e->act16 + (size_t)b0 * I;
         a.res = h; a.out = h; a.ld_out = H;
         if (pgk_status r = batched_proj(FP8, PRO_PLAIN, EPI_RESID, a, M, st)) return r;
-        *launches += ((direct || e->merge_cnt) ? 5 : 6) + (tiled ? 2 : 0);
+        *launches += ((direct || e->merge_cnt) ? 5 : 6) + (tiled ? 2 : 0) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;
     }
     const int nblk = ceil_div(c.vocab_size, 16) < 2048 ? ceil_div(c.vocab_size, 16) : 2048;
     mark(KC_LMHEAD);
@@ -1434,7 +1462,7 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
     PGK_REQUIRE(c.head_dim == 128 || c.head_dim == 64, "pgk_engine_create: head_dim %d not in {64,128}", c.head_dim);
     PGK_REQUIRE(c.num_heads % c.num_kv_heads == 0, "pgk_engine_create: Hq %d %% Hkv %d", c.num_heads, c.num_kv_heads);
     const int G = c.num_heads / c.num_kv_heads;
-    PGK_REQUIRE(G == 1 || G == 2 || G == 4, "pgk_engine_create: GQA group %d not in {1,2,4}", G);
+    PGK_REQUIRE(G >= 1, "pgk_engine_create: GQA group %d", G);
     PGK_REQUIRE(c.hidden_size % 16 == 0 && c.intermediate_size % 16 == 0, "pgk_engine_create: sizes must be multiples of 16");
     PGK_REQUIRE(c.weight_format == 0 || (c.hidden_size % 128 == 0 && c.intermediate_size % 128 == 0),
                 "pgk_engine_create: fp8 weights need 128-multiple dims");
@@ -1467,7 +1495,7 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
 #endif
         const char* env = getenv("PGK_FUSED_ATTN");
         const bool want = env ? atoi(env) != 0 : true;
-        e->fused_attn = want && tiles && c.weight_format == 0 && c.max_seq_len <= 512;
+        e->fused_attn = want && tiles && c.weight_format == 0 && c.max_seq_len <= 512 && (G == 1 || G == 2 || G == 4);
         e->oproj_rows = rows;
     }
     const int B = c.max_batch, H = c.hidden_size, D = c.head_dim;
@@ -1515,7 +1543,7 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         // Off by default: measured at context 2048 the release/acquire hand-off costs more than the kernel boundary it
         // replaces (attention phase 13.9 us vs 11.4 us with the separate 4.7 us merge kernel; 1118 vs 1240 tok/s).
         const char* em = getenv("PGK_ATTN_INKERNEL_MERGE");
-        if (em && atoi(em) == 1) {
+        if (em && atoi(em) == 1 && (G == 1 || G == 2 || G == 4)) {
             A((void**)&e->merge_cnt, (size_t)B * c.num_kv_heads * 4, &e->ws_bytes);
             if (e->merge_cnt) PGK_CHECK_HIP(hipMemset(e->merge_cnt, 0, (size_t)B * c.num_kv_heads * 4));
         }

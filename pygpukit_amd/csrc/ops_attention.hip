@@ -10,6 +10,8 @@
 
 #include <type_traits>
 
+#include <cstring>
+
 #include "attn_core.cuh"
 #include "pgk_internal.h"
 
@@ -272,6 +274,21 @@ pgk_status flash_prefill(const void* q, const void* k, const void* v, void* out,
                          float scale, long long qh, long long qs, long long kh, long long ks, long long oh, long long os,
                          int dt16, hipStream_t st);
 
+// The reference's A/B switches, same names and values (native/ops/nn/attention/sdpa_causal.inl:380-447), read per call:
+//   PYGPUKIT_FLASH_ATTENTION  "0"/"false": never the tiled MFMA flash kernels (one-workgroup-per-row fallback, kv_len <= 15360);
+//                             "1"/"true" or unset/"auto": flash whenever the layout allows it (there is no length threshold
+//                             here: the fallback is never faster on this chip)
+//   PYGPUKIT_FLASH_DECODING   0: single-token attention over a fixed cache takes the general path instead of split-KV
+//                             flash-decoding (only possible with a host context length); 1 / -1 / unset: split-KV
+static bool flash_attention_off() {
+    const char* e = getenv("PYGPUKIT_FLASH_ATTENTION");
+    return e && (strcmp(e, "0") == 0 || strcmp(e, "false") == 0);
+}
+static bool flash_decoding_off() {
+    const char* e = getenv("PYGPUKIT_FLASH_DECODING");
+    return e && atoi(e) == 0 && strcmp(e, "auto") != 0;
+}
+
 // 0 = first-generation kernel only, 1 = second-generation (ops_flash.hip) whenever it applies; default: by size
 static int flash_gen_choice() {
     static const int v = [] { const char* e = getenv("PGK_FLASH_GEN"); return e ? atoi(e) : -1; }();
@@ -282,7 +299,7 @@ template <class T>
 static pgk_status sdpa_dispatch(const void* q, const void* k, const void* v, void* out, int hq, int hkv, int q_len,
                                 int kv_len, int d, float scale, const AttnStrides& sd, hipStream_t st) {
     const bool mfma_ok = !std::is_same<T, float>::value && (d == 64 || d == 128) && aligned16(q) && aligned16(k) &&
-                         aligned16(v) && sd.qs % 8 == 0 && sd.ks % 8 == 0 && sd.qh % 8 == 0 && sd.kh % 8 == 0;
+                         aligned16(v) && sd.qs % 8 == 0 && sd.ks % 8 == 0 && sd.qh % 8 == 0 && sd.kh % 8 == 0 && !flash_attention_off();
     if constexpr (!std::is_same<T, float>::value) {
         // second generation: 128-row query tiles, transposed-score orientation (ops_flash.hip); the first-generation
         // kernel keeps the short prompts, where its 64-row tiles give twice the workgroups
@@ -339,7 +356,8 @@ pgk_status pgk_sdpa_fixed_cache(const void* q, const void* k_cache, const void* 
     if (scale <= 0.f) scale = 1.0f / sqrtf((float)d);
     hipStream_t st = resolve_stream(s);
     const int rep = hq / hc;
-    const bool fast = q_len == 1 && (d == 128 || d == 64) && workspace && aligned16(q) && aligned16(k_cache) && aligned16(v_cache);
+    const bool fast = q_len == 1 && (d == 128 || d == 64) && workspace && aligned16(q) && aligned16(k_cache) && aligned16(v_cache) &&
+                      !(flash_decoding_off() && !ctx_buf);
     if (fast) {
         const int nsplit = decode_nsplit(max_seq);
         int G = 1;

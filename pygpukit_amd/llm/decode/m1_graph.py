@@ -19,6 +19,7 @@ class DecodeM1Graph(DecodeStrategy):
         self._engine = None
         self._graph_ready = False
         self._graph_max_seq_len = 0
+        self._decode_buffers = None
 
     def step(self, token_id, position, context_len, buffers):
         raise NotImplementedError("DecodeM1Graph does not support non-graph decode. Use DecodeM1, or call "
@@ -28,6 +29,7 @@ class DecodeM1Graph(DecodeStrategy):
         self._engine = self.model.build_engine(max_seq_len=max_seq_len, max_batch=1)
         self._engine.capture(1)
         self._graph_max_seq_len = max_seq_len
+        self._decode_buffers = None
         self._graph_ready = True
 
     def has_graph(self) -> bool:
@@ -39,7 +41,23 @@ class DecodeM1Graph(DecodeStrategy):
 
     @property
     def buffers(self):
-        return None
+        """The strategy's DecodeBuffers (reference: m1_graph.py:67,248-262 allocates them in init_graph and its graphs
+        run on them).  Here the whole step runs inside the native engine on the engine's own fp32 intermediates, so
+        the object exists for code that addresses buffers by name: `logits`, `token_id_buf` and `position_buf` ARE the
+        engine's live device state (the step's fp32 logits; the token / position the next replay consumes, updated
+        by every replay); the per-layer activation fields have the reference's names and shapes but no step writes
+        them (INTEGRATION.md)."""
+        if not self._graph_ready:
+            return None
+        if self._decode_buffers is None:
+            from pygpukit_amd.llm.buffers import DecodeBuffers
+
+            spec = getattr(self.model, "spec", None)
+            b = DecodeBuffers.allocate(self.model.config, dtype="bfloat16", use_qk_norm=bool(spec is not None and spec.use_qk_norm))
+            b.logits = self._engine.logits(1)
+            b.token_id_buf, b.position_buf = self._engine.state_arrays(1)
+            self._decode_buffers = b
+        return self._decode_buffers
 
     def prefill(self, input_ids: list[int]) -> np.ndarray:
         """Fill the engine's KV cache from the prompt; returns the last row's fp32 logits."""

@@ -687,6 +687,42 @@ def test_sdpa_fixed_cache_decode(dt, cfg):
     np.testing.assert_array_equal(out2.to_numpy(), out.to_numpy())
 
 
+def test_reference_flash_switches_select_other_kernels_with_the_same_result(monkeypatch):
+    """PYGPUKIT_FLASH_ATTENTION / PYGPUKIT_FLASH_DECODING are the reference's A/B switches (sdpa_causal.inl:380-447): with
+    them off the one-workgroup-per-row fallback resp. the general SDPA path run instead of the MFMA flash / split-KV
+    kernels; results agree to the bf16 bar either way."""
+    rng = np.random.default_rng(14)
+    hq, hkv, s_len, d = 4, 2, 200, 128
+    q = rng.standard_normal((hq, s_len, d)).astype(np.float32)
+    k, v = (rng.standard_normal((hkv, s_len, d)).astype(np.float32) for _ in range(2))
+    ref = O.sdpa_causal(O.bf16_round(q), np.repeat(O.bf16_round(k), hq // hkv, axis=0), np.repeat(O.bf16_round(v), hq // hkv, axis=0), 0.0)
+    outs = {}
+    for mode in ("auto", "0", "1"):
+        monkeypatch.setenv("PYGPUKIT_FLASH_ATTENTION", mode)
+        outs[mode] = host(ops.sdpa_causal(dev(q, "bfloat16"), dev(np.repeat(k, hq // hkv, axis=0), "bfloat16"),
+                                          dev(np.repeat(v, hq // hkv, axis=0), "bfloat16")))
+        close(outs[mode], ref, "bfloat16")
+    np.testing.assert_array_equal(outs["auto"], outs["1"])
+    assert not np.array_equal(outs["auto"], outs["0"])          # another kernel, another rounding order
+    monkeypatch.delenv("PYGPUKIT_FLASH_ATTENTION")
+    max_seq, ctx = 256, 131
+    q1 = rng.standard_normal((hq, 1, d)).astype(np.float32)
+    kc, vc = (rng.standard_normal((hkv, max_seq, d)).astype(np.float32) for _ in range(2))
+    ref1 = O.sdpa_causal_fixed_cache(O.bf16_round(q1), O.bf16_round(kc), O.bf16_round(vc), ctx)
+    dec = {}
+    for mode in ("-1", "0", "1"):
+        monkeypatch.setenv("PYGPUKIT_FLASH_DECODING", mode)
+        out = pk.empty((hq, 1, d), "bfloat16")
+        ops.sdpa_causal_fixed_cache(dev(q1, "bfloat16"), dev(kc, "bfloat16"), dev(vc, "bfloat16"), out, ctx)
+        dec[mode] = host(out)
+        close(dec[mode], ref1, "bfloat16")
+    np.testing.assert_array_equal(dec["-1"], dec["1"])
+    # a device-resident context length has only the split-KV kernel: "0" must not break it
+    out = pk.empty((hq, 1, d), "bfloat16")
+    ops.sdpa_causal_fixed_cache_ptr(dev(q1, "bfloat16"), dev(kc, "bfloat16"), dev(vc, "bfloat16"), out, from_numpy(np.array([ctx], np.int32)), max_seq)
+    np.testing.assert_array_equal(host(out), dec["1"])
+
+
 def test_sdpa_fixed_cache_multi_query():
     rng = np.random.default_rng(13)
     hq, hc, d, max_seq, ctx, ql = 4, 2, 128, 96, 50, 5

@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpgk_hip.so")
+LIB_PATH = os.environ.get("PGK_LIB") or os.path.join(_HERE, "libpgk_hip.so")     # PGK_LIB: a diagnostic build of the same library
 
 c_void_pp = C.POINTER(C.c_void_p)
 c_i32_p = C.POINTER(C.c_int32)

@@ -107,63 +107,105 @@ template <int D, int U, int NWV = 4>
 __device__ __forceinline__ void kv_issue(KVBatch<U>& kb, const bf16* kbase, const bf16* vbase, int p0, int clamp_max, int lane) {
     constexpr int LPR = D / 8, PPW = 64 / LPR, STRIDE = NWV * PPW;
     const int grp = lane / LPR, sub = lane % LPR;
+    // every K row first, then the V rows: vector memory returns in issue order, so the scores (K only) run while the V
+    // half of the batch is still arriving, instead of starting when the last byte of the batch has landed
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int pc = min(p0 + u * STRIDE + grp, clamp_max);
         kb.k[u] = *reinterpret_cast<const uint4*>(kbase + (size_t)pc * D + sub * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int pc = min(p0 + u * STRIDE + grp, clamp_max);
         kb.v[u] = *reinterpret_cast<const uint4*>(vbase + (size_t)pc * D + sub * 8);
     }
 }
 
+// bf16 pairs for v_dot2_f32_bf16 (products exact in fp32, fp32 accumulate)
+typedef __bf16 attn_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float attn_dot2(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(attn_bf16x2, a), __builtin_bit_cast(attn_bf16x2, b), acc, false);
+}
+
+// Scores and P.V on the packed bf16 dot instruction, straight from the cache's bf16 words - no widening of K or V:
+//   score  = 4 x dot2(k pair, q pair)           q rounded to bf16 once per step (the model's dtype; flash prefill does the same)
+//   o[j]  += dot2((v_u[j], v_u'[j]), (p_u, p_u'))  two cached positions per instruction: the V words of two rows are
+//            interleaved by v_perm_b32 (shared by the G heads), the two probabilities packed to bf16
+// 28 VALU instructions per position and lane-group at G = 2 where the fp32 version (8 + 8 widenings, 16 + 16 FMAs ...) took 75:
+// the kernel's attention phase went from 1.96 to ~1 us (in-kernel stamps, tools/phase_stamps.py).  Position-groups that lie
+// wholly beyond the context (the first batch is issued for U0 groups before the length is known) are skipped by a
+// wave-uniform branch.  Batch-wise softmax as before: all scores first, ONE running-max update and one rescale per batch.
 template <int D, int G, int U, int NWV = 4>
-__device__ __forceinline__ void kv_consume(const KVBatch<U>& kb, int p0, int c1, const float (&qf)[G][8], int lane,
+__device__ __forceinline__ void kv_consume(const KVBatch<U>& kb, int p0, int c1, const uint4 (&qb)[G], int lane,
                                            DecodeState<G>& st) {
     constexpr int LPR = D / 8, PPW = 64 / LPR, STRIDE = NWV * PPW;
+    static_assert(U % 2 == 0, "positions are consumed in pairs");
     const int grp = lane / LPR;
-    // batch-wise softmax: all U scores first (independent dot products), ONE running-max update and one
-    // rescale per batch - a short dependency chain instead of U chained exp/rescale steps.
     float s[U][G];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const bool valid = p0 + u * STRIDE + grp < c1;
-        Vec<bf16> kv;
-        kv.raw = kb.k[u];
-        float kf[8];
-        kv.to_float(kf);
+        const bool live = p0 + u * STRIDE < c1;            // wave-uniform: some lane-group of this wave has a valid position
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float d = 0.f;
+        for (int g = 0; g < G; ++g) s[u][g] = -INFINITY;
+        if (live) {
+            const bool valid = p0 + u * STRIDE + grp < c1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d = fmaf(qf[g][j], kf[j], d);
-            d = group_sum<LPR>(d);
-            s[u][g] = valid ? d : -INFINITY;
+            for (int g = 0; g < G; ++g) {
+                float d = attn_dot2(kb.k[u].x, qb[g].x, 0.f);
+                d = attn_dot2(kb.k[u].y, qb[g].y, d);
+                d = attn_dot2(kb.k[u].z, qb[g].z, d);
+                d = attn_dot2(kb.k[u].w, qb[g].w, d);
+                d = group_sum<LPR>(d);
+                s[u][g] = valid ? d : -INFINITY;
+            }
+        }
+    }
+    float mx[G], alpha[G], lsum[G];
+    bool any[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        mx[g] = st.m[g];
+#pragma unroll
+        for (int u = 0; u < U; ++u) mx[g] = fmaxf(mx[g], s[u][g]);
+        any[g] = mx[g] != -INFINITY;                        // nothing valid yet for this lane-group: leave the state alone
+        alpha[g] = any[g] ? __expf(st.m[g] - mx[g]) : 1.f;
+        lsum[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) st.o[g][j] *= alpha[g];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u += 2) {
+        if (p0 + u * STRIDE < c1) {                         // wave-uniform
+            // (v_u[j], v_u'[j]) pairs: word i of a row holds dims 2i (low half) and 2i + 1 (high half)
+            const uint32_t a[4] = {kb.v[u].x, kb.v[u].y, kb.v[u].z, kb.v[u].w};
+            const uint32_t b[4] = {kb.v[u + 1].x, kb.v[u + 1].y, kb.v[u + 1].z, kb.v[u + 1].w};
+            uint32_t ve[4], vo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ve[i] = __builtin_amdgcn_perm(b[i], a[i], 0x05040100u);   // {a.lo16, b.lo16}
+                vo[i] = __builtin_amdgcn_perm(b[i], a[i], 0x07060302u);   // {a.hi16, b.hi16}
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float pa = any[g] ? __expf(s[u][g] - mx[g]) : 0.f;        // exp(-inf) = 0 for masked positions
+                const float pb = any[g] ? __expf(s[u + 1][g] - mx[g]) : 0.f;
+                const uint32_t pk = pack_bf16x2(pa, pb);
+                // the denominator sums the ROUNDED probabilities, the ones the numerator uses
+                lsum[g] += __uint_as_float(pk << 16) + __uint_as_float(pk & 0xFFFF0000u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    st.o[g][2 * i] = attn_dot2(ve[i], pk, st.o[g][2 * i]);
+                    st.o[g][2 * i + 1] = attn_dot2(vo[i], pk, st.o[g][2 * i + 1]);
+                }
+            }
         }
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        float mx = st.m[g];
-#pragma unroll
-        for (int u = 0; u < U; ++u) mx = fmaxf(mx, s[u][g]);
-        if (mx == -INFINITY) continue;  // nothing valid yet for this lane-group
-        const float alpha = __expf(st.m[g] - mx);
-        float lsum = 0.f, acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = st.o[g][j] * alpha;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float pw = __expf(s[u][g] - mx);  // exp(-inf) = 0 for masked positions
-            lsum += pw;
-            Vec<bf16> vv;
-            vv.raw = kb.v[u];
-            float vf[8];
-            vv.to_float(vf);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(pw, vf[j], acc[j]);
+        if (any[g]) {
+            st.l[g] = st.l[g] * alpha[g] + lsum[g];
+            st.m[g] = mx[g];
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) st.o[g][j] = acc[j];
-        st.l[g] = st.l[g] * alpha + lsum;
-        st.m[g] = mx;
     }
 }
 
@@ -171,14 +213,14 @@ __device__ __forceinline__ void kv_consume(const KVBatch<U>& kb, int p0, int c1,
 // flight together, ONE softmax rescale per trip.  U = 8 covers 128 positions (D = 128) per trip, so a split-KV slice of
 // the usual 64-100 positions is one memory round trip (the per-position walk above made two, the second nearly empty).
 template <int D, int G, int U = 8, int NWV = 4>
-__device__ __forceinline__ void decode_walk_trips(const bf16* kbase, const bf16* vbase, int c0, int c1, const float (&qf)[G][8],
+__device__ __forceinline__ void decode_walk_trips(const bf16* kbase, const bf16* vbase, int c0, int c1, const uint4 (&qb)[G],
                                                   int lane, int wid, DecodeState<G>& st) {
     constexpr int LPR = D / 8, PPW = 64 / LPR, STRIDE = NWV * PPW;
     for (int b0 = c0; b0 < c1; b0 += U * STRIDE) {          // workgroup-uniform trip count
         const int p0 = b0 + wid * PPW;                      // this wave's first position of the trip
         KVBatch<U> kb;
         kv_issue<D, U, NWV>(kb, kbase, vbase, p0, c1 - 1, lane);
-        kv_consume<D, G, U, NWV>(kb, p0, c1, qf, lane, st);
+        kv_consume<D, G, U, NWV>(kb, p0, c1, qb, lane, st);
     }
 }
 
@@ -219,6 +261,8 @@ __device__ __forceinline__ void decode_block_merge(const DecodeState<G>& st, flo
 
 // Same merge, but the workgroup saw the WHOLE context: write the normalised attention output
 // attn[g*D + d] into LDS (`attn_out`, G*D floats) for a consumer inside the same kernel.
+// (Tried: folding the lane-groups of a wave with xor-shuffles first, so that only one record per wave crosses LDS - 40
+// dependent ds_bpermutes per wave took longer than the 16-slot LDS pass they replaced, 1.04 vs 0.78 us in the fused kernel.)
 template <int D, int G, int NWV = 4>
 __device__ __forceinline__ void decode_block_merge_lds(const DecodeState<G>& st, float* lds, float* attn_out, int lane,
                                                        int wid) {

@@ -83,33 +83,42 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
     float psc[R][C > 0 ? C : 1];
     float resv[R][M];
     if constexpr (C > 0) {
-        // ---- all global loads of the first trip, issued back to back ----
+        // ---- all global loads of the first trip, issued back to back; nothing is waited for until the prologue's ALU ----
+        // Vector memory returns in ISSUE order.  The activation vectors are a few KB that the previous kernel left in L2,
+        // the weight rows come from HBM: issued first, the activations are usable ~1 us before the weights land and the
+        // whole prologue (norm statistic, barrier, LDS image) runs under the weight latency.  (The first version issued
+        // the weights first: the prologue then started only after the last weight chunk had arrived - in-kernel stamps,
+        // tools/phase_stamps.py.)  In a dual chain the activations do not exist yet: weights, then the wait, then them.
         const int nf = min(wave * OUT_PER_TRIP, N - 1);  // waves beyond N recompute the last rows (never stored)
+        auto load_weights = [&]() {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int row = row_of(nf, r);
-            const WT* wr = reinterpret_cast<const WT*>(a.w) + (size_t)row * KC;
+            for (int r = 0; r < R; ++r) {
+                const int row = row_of(nf, r);
+                const WT* wr = reinterpret_cast<const WT*>(a.w) + (size_t)row * KC;
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int k0 = lane * NW + c * 64 * NW;
-                pre[r][c] = load_nt16(wr + k0);
-                if constexpr (FP8) psc[r][c] = to_f(a.wscale[(size_t)(row >> 7) * (KC >> 7) + (k0 >> 7)]);
+                for (int c = 0; c < C; ++c) {
+                    const int k0 = lane * NW + c * 64 * NW;
+                    pre[r][c] = load_nt16(wr + k0);
+                    if constexpr (FP8) psc[r][c] = to_f(a.wscale[(size_t)(row >> 7) * (KC >> 7) + (k0 >> 7)]);
+                }
             }
+        };
+        if constexpr (DUAL) {
+            load_weights();
+            dep_wait(a.dep);       // every load of bytes another kernel of this step wrote is an sc1 load from here on
         }
-        // ---- the weights are on their way: now wait for the kernel that produces the activations (dual chain) ----
-        if constexpr (DUAL) dep_wait(a.dep);
-        // dual chain: every load of bytes another kernel of this step wrote is an sc1 load (engine_common.cuh)
+        constexpr bool NORM = PRO == PRO_NORM || PRO == PRO_NORM_SUM;
+        constexpr int NP = (PRO == PRO_NORM_SUM) ? 8 : 1;
+        const int np = (PRO == PRO_NORM_SUM) ? a.nsplit : 1;
+        float hv[M][KJ], gv[NORM ? KJ : 1], pvs[PRO == PRO_NORM_SUM ? M : 1][PRO == PRO_NORM_SUM ? KJ : 1][NP];
+        // ---- activation loads ----
         if constexpr (EPI == EPI_RESID) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int m = 0; m < M; ++m) resv[r][m] = ld_act(a.res + (size_t)m * a.ld_out + min(nf + r, N - 1), coh);
         }
-        // ---- prologue, exact trip counts ----
-        if constexpr (PRO == PRO_NORM || PRO == PRO_NORM_SUM) {
-            constexpr int NP = (PRO == PRO_NORM_SUM) ? 8 : 1;
-            const int np = (PRO == PRO_NORM_SUM) ? a.nsplit : 1;
-            float hv[M][KJ], gv[KJ];
+        if constexpr (NORM) {
 #pragma unroll
             for (int j = 0; j < KJ; ++j) {
                 const int i = threadIdx.x + 256 * j;
@@ -118,18 +127,35 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
                 for (int m = 0; m < M; ++m) hv[m][j] = ld_act(a.h + (size_t)m * KC + i, coh);
             }
             if constexpr (PRO == PRO_NORM_SUM) {
-                // partial vectors: unconditional clamped loads, masked adds (one round trip for up to 8)
+                // partial vectors: unconditional clamped loads, masked adds below (one round trip for up to 8)
 #pragma unroll
                 for (int m = 0; m < M; ++m)
 #pragma unroll
-                    for (int j = 0; j < KJ; ++j) {
-                        float pv[NP];
+                    for (int j = 0; j < KJ; ++j)
 #pragma unroll
                         for (int p = 0; p < NP; ++p)
-                            pv[p] = ld_act(a.part + ((size_t)m * np + min(p, np - 1)) * KC + threadIdx.x + 256 * j, coh);
+                            pvs[m][j][p] = ld_act(a.part + ((size_t)m * np + min(p, np - 1)) * KC + threadIdx.x + 256 * j, coh);
+            }
+        } else if constexpr (PRO == PRO_PLAIN) {
 #pragma unroll
-                        for (int p = 0; p < NP; ++p) hv[m][j] += (p < np) ? pv[p] : 0.f;
-                    }
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) hv[m][j] = ld_act(a.xin + (size_t)m * KC + threadIdx.x + 256 * j, coh);
+        }
+        if constexpr (!DUAL) {
+            __builtin_amdgcn_sched_barrier(0);      // keep the compiler from hoisting the weight stream above the small loads
+            load_weights();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- prologue ALU, exact trip counts ----
+        if constexpr (NORM) {
+            if constexpr (PRO == PRO_NORM_SUM) {
+#pragma unroll
+                for (int m = 0; m < M; ++m)
+#pragma unroll
+                    for (int j = 0; j < KJ; ++j)
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) hv[m][j] += (p < np) ? pvs[m][j][p] : 0.f;
             }
             float ss[M];
 #pragma unroll
@@ -156,15 +182,10 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
                 }
             }
         } else if constexpr (PRO == PRO_PLAIN) {
-            float xv[M][KJ];
 #pragma unroll
             for (int m = 0; m < M; ++m)
 #pragma unroll
-                for (int j = 0; j < KJ; ++j) xv[m][j] = ld_act(a.xin + (size_t)m * KC + threadIdx.x + 256 * j, coh);
-#pragma unroll
-            for (int m = 0; m < M; ++m)
-#pragma unroll
-                for (int j = 0; j < KJ; ++j) store_x<XT>(xs, m * KC + threadIdx.x + 256 * j, xv[m][j]);
+                for (int j = 0; j < KJ; ++j) store_x<XT>(xs, m * KC + threadIdx.x + 256 * j, hv[m][j]);
         }
     }
     if constexpr (C == 0 || PRO == PRO_ATTN) {
@@ -469,37 +490,65 @@ struct AttnArgs {
 
 template <int D, int G>
 struct NewToken {
-    float qf[G][8], kn[8], vn[8];
-    uint4 kbits, vbits;
+    float qf[G][8], kn[8], vn[8];   // q (pre-scaled) and k, v of the new token, all as the bf16-rounded values every consumer sees
+    uint4 qb[G], kbits, vbits;      // the same as packed bf16
+};
+
+// The new token's q/k/v, in two steps so that a kernel can put other loads between them: (1) every load - the fp32 q/k/v
+// row slices of this lane, the QK-norm gammas, the RoPE row - issued back to back, nothing waited for; (2) pure ALU.
+// Vector memory returns in issue order, so whatever is loaded FIRST is usable first: the fused kernel issues these small
+// L2-resident loads ahead of its K/V and W_o streams and runs step (2) while those are still in flight.
+template <int G>
+struct NewTokenRaw {
+    float4 lo[G + 2], hi[G + 2];   // q heads, k, v: this lane's 8 dims
+    uint4 gq, gk;                  // 8 bf16 gammas each
+    float4 cs[2], sn[2];           // RoPE row slice
 };
 
 template <int D, int G, bool COH = false>
-__device__ __forceinline__ void prepare_new_token(const AttnArgs& a, int b, int kvh, int pos, int lane, NewToken<D, G>& t) {
+__device__ __forceinline__ void new_token_load(const AttnArgs& a, int b, int kvh, int lane, NewTokenRaw<G>& r) {
     constexpr int LPR = D / 8, HALF = D / 2;
     const int sub = lane % LPR;
     const float* row = a.qkv + (size_t)b * a.qkv_ld;
-    constexpr bool coh = COH;
-    const float* cs = a.rope_cos + (size_t)b * HALF;   // address independent of pos: no extra round trip
-    const float* sn = a.rope_sin + (size_t)b * HALF;
-    // all loads first (q heads, k, v, gammas, rope row): one memory round trip, then pure ALU
-    float raw[G + 2][8], gq[8], gk[8], csv[8], snv[8];
 #pragma unroll
     for (int g = 0; g < G + 2; ++g) {
-        // q/k/v come from the previous kernel of this step: sc1 loads (dual chain, engine_common.cuh)
+        // q/k/v come from the previous kernel of this step: sc1 loads in a dual chain (engine_common.cuh)
         const unsigned eoff = (g < G) ? (unsigned)(kvh * a.g_total + a.g_off + g) * D : (g == G ? (unsigned)(a.hq + kvh) * D : (unsigned)(a.hq + a.hkv + kvh) * D);
-        const float4 u = ld_act4(row, eoff + sub * 8, coh), v = ld_act4(row, eoff + sub * 8 + 4, coh);
-        raw[g][0] = u.x; raw[g][1] = u.y; raw[g][2] = u.z; raw[g][3] = u.w;
-        raw[g][4] = v.x; raw[g][5] = v.y; raw[g][6] = v.z; raw[g][7] = v.w;
+        r.lo[g] = ld_act4(row, eoff + sub * 8, COH);
+        r.hi[g] = ld_act4(row, eoff + sub * 8 + 4, COH);
+    }
+    r.gq = r.gk = make_uint4(0, 0, 0, 0);
+    if (a.q_gamma != nullptr) {
+        r.gq = *reinterpret_cast<const uint4*>(a.q_gamma + sub * 8);
+        r.gk = *reinterpret_cast<const uint4*>(a.k_gamma + sub * 8);
+    }
+    const int dd = (sub * 8) % HALF;                    // the lane's 8 dims stay inside one half (8 | HALF)
+    const float* cs = a.rope_cos + (size_t)b * HALF + dd;   // address independent of the position: no extra round trip
+    const float* sn = a.rope_sin + (size_t)b * HALF + dd;
+    r.cs[0] = *reinterpret_cast<const float4*>(cs); r.cs[1] = *reinterpret_cast<const float4*>(cs + 4);
+    r.sn[0] = *reinterpret_cast<const float4*>(sn); r.sn[1] = *reinterpret_cast<const float4*>(sn + 4);
+}
+
+template <int D, int G>
+__device__ __forceinline__ void new_token_finish(const AttnArgs& a, int lane, const NewTokenRaw<G>& r, NewToken<D, G>& t) {
+    constexpr int LPR = D / 8;
+    const int sub = lane % LPR;
+    float raw[G + 2][8], gq[8], gk[8];
+#pragma unroll
+    for (int g = 0; g < G + 2; ++g) {
+        raw[g][0] = r.lo[g].x; raw[g][1] = r.lo[g].y; raw[g][2] = r.lo[g].z; raw[g][3] = r.lo[g].w;
+        raw[g][4] = r.hi[g].x; raw[g][5] = r.hi[g].y; raw[g][6] = r.hi[g].z; raw[g][7] = r.hi[g].w;
     }
     const bool has_norm = a.q_gamma != nullptr;
+    if (has_norm) {
+        WTraits<bf16>::decode(r.gq, gq);
+        WTraits<bf16>::decode(r.gk, gk);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        gq[j] = has_norm ? to_f(a.q_gamma[sub * 8 + j]) : 1.f;
-        gk[j] = has_norm ? to_f(a.k_gamma[sub * 8 + j]) : 1.f;
-        const int dd = (sub * 8 + j) % HALF;
-        csv[j] = cs[dd];
-        snv[j] = sn[dd];
+        for (int j = 0; j < 8; ++j) gq[j] = gk[j] = 1.f;
     }
+    const float csv[8] = {r.cs[0].x, r.cs[0].y, r.cs[0].z, r.cs[0].w, r.cs[1].x, r.cs[1].y, r.cs[1].z, r.cs[1].w};
+    const float snv[8] = {r.sn[0].x, r.sn[0].y, r.sn[0].z, r.sn[0].w, r.sn[1].x, r.sn[1].y, r.sn[1].z, r.sn[1].w};
     // norm + rope of one head vector; this lane holds dims sub*8..+8, the rotate-half partner dims live
     // LPR/2 lanes away.
     auto norm_rope = [&](const float (&xin)[8], const float (&gamma)[8], float (&o)[8]) {
@@ -527,6 +576,10 @@ __device__ __forceinline__ void prepare_new_token(const AttnArgs& a, int b, int 
         norm_rope(raw[g], gq, t.qf[g]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) t.qf[g][j] *= a.scale;
+        Vec<bf16> qv;                   // q is bf16 from here on (the model's dtype): scores run on the packed bf16 dot
+        qv.from_float(t.qf[g]);
+        qv.to_float(t.qf[g]);
+        t.qb[g] = qv.raw;
     }
     norm_rope(raw[G], gk, t.kn);
 #pragma unroll
@@ -539,6 +592,13 @@ __device__ __forceinline__ void prepare_new_token(const AttnArgs& a, int b, int 
     vb.to_float(t.vn);
     t.kbits = kb.raw;
     t.vbits = vb.raw;
+}
+
+template <int D, int G, bool COH = false>
+__device__ __forceinline__ void prepare_new_token(const AttnArgs& a, int b, int kvh, int pos, int lane, NewToken<D, G>& t) {
+    NewTokenRaw<G> r;
+    new_token_load<D, G, COH>(a, b, kvh, lane, r);
+    new_token_finish<D, G>(a, lane, r, t);
 }
 
 template <int D, int G>
@@ -561,7 +621,7 @@ template <int D, int G, bool DIRECT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned long long* tl) {
     const TLStamp tls(tl);
     constexpr int LPR = D / 8, PPW = 64 / LPR, RS = D + 2;
-    __shared__ float lds[4 * PPW * G * RS];
+    __shared__ __attribute__((aligned(16))) float lds[4 * PPW * G * RS];
     __shared__ float attn_out[DIRECT ? G * D : 1];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane % LPR;
     const int kvh = blockIdx.y, b = blockIdx.z;
@@ -574,7 +634,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
         constexpr int U0 = 12;
         KVBatch<U0> kb0;
         kv_issue<D, U0, 4>(kb0, a.kcache + head_off, a.vcache + head_off, wid * PPW, a.max_seq - 1, lane);
-        const int pos = a.positions[b];
+        const int pos = load_uniform_i32(a.positions + b);   // scalar path (pgk_device.cuh): not queued behind the vector loads in flight
         NewToken<D, G> t;
         prepare_new_token<D, G>(a, b, kvh, pos, lane, t);
         if (pos < a.max_seq && wid == 0 && lane < LPR && a.g_off == 0) {
@@ -584,8 +644,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
         DecodeState<G> st;
         st.init();
         const int c1 = min(pos, a.max_seq);
-        kv_consume<D, G, U0, 4>(kb0, wid * PPW, c1, t.qf, lane, st);
-        if (c1 > U0 * 4 * PPW) decode_walk_trips<D, G>(a.kcache + head_off, a.vcache + head_off, U0 * 4 * PPW, c1, t.qf, lane, wid, st);
+        kv_consume<D, G, U0, 4>(kb0, wid * PPW, c1, t.qb, lane, st);
+        if (c1 > U0 * 4 * PPW) decode_walk_trips<D, G>(a.kcache + head_off, a.vcache + head_off, U0 * 4 * PPW, c1, t.qb, lane, wid, st);
         if (pos < a.max_seq && wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
         decode_block_merge_lds<D, G>(st, lds, attn_out, lane, wid);
         if (a.attn_direct16) {
@@ -596,7 +656,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
         tls.end();
         return;
     }
-    const int pos = a.positions[b];
+    const int pos = load_uniform_i32(a.positions + b);   // scalar path (pgk_device.cuh): not queued behind the vector loads in flight
     const int ctx = min(pos + 1, a.max_seq);
     NewToken<D, G> t;
     prepare_new_token<D, G>(a, b, kvh, pos, lane, t);
@@ -609,7 +669,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
     }
     DecodeState<G> st;
     st.init();
-    decode_walk_trips<D, G>(a.kcache + head_off, a.vcache + head_off, c0, owns_new ? min(c1, pos) : c1, t.qf, lane, wid, st);
+    decode_walk_trips<D, G>(a.kcache + head_off, a.vcache + head_off, c0, owns_new ? min(c1, pos) : c1, t.qb, lane, wid, st);
     if (owns_new && wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
     if constexpr (DIRECT) {
         // this workgroup saw the whole context: normalise here and skip the merge launch
@@ -715,7 +775,7 @@ __global__ void attn_merge_kernel(const float* part, float* attn, int hq, int ns
     tls.end();
 }
 
-// fused path: grid (H / rows_per_block, Hkv, batch), 256 threads.  Every workgroup of a KV head recomputes
+// fused path: grid ((H / rows_per_block) * Hkv, 1, batch), 256 threads.  Every workgroup of a KV head recomputes
 // that head's (short-context) attention from L2-resident K/V, then multiplies it with ITS slice of W_o
 // (rows_per_block output rows x G*D columns), whose loads were issued before anything else.
 template <int D, int G, bool DUAL = false>
@@ -727,41 +787,61 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a, unsigned lo
     constexpr int RPP = NWV * 64 / LPW;              // rows per pass of the workgroup
     constexpr int PRE = 4;                           // preloaded passes
     constexpr int U0 = 12;                           // position-groups per wave in the first KV batch
-    __shared__ float lds[NWV * PPW * G * RS];
+    __shared__ __attribute__((aligned(16))) float lds[NWV * PPW * G * RS];
     __shared__ __attribute__((aligned(16))) float attn[GD];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane % LPR;
-    const int kvh = blockIdx.y, b = blockIdx.z;
-    const int r0 = blockIdx.x * a.rows_per_block;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPR;   // wid in an SGPR: per-wave branches stay scalar
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs in linear order, so with the kv head as the
+    // FASTEST index all row slices of kv head h land on XCD h % 8 and its K/V rows are fetched into ONE L2 instead of eight
+    // (PMC: 9.6 MB of HBM traffic per launch for 4.9 MB of algorithmic bytes with the row slice fastest).  Speed only.
+    const int kvh = blockIdx.x % a.hkv, rb = blockIdx.x / a.hkv, b = blockIdx.z;
+    const int r0 = rb * a.rows_per_block;
     const int lr = threadIdx.x % LPW, rip = threadIdx.x / LPW;
     const int npass = a.rows_per_block / RPP;
     const bf16* wbase = a.w_o + (size_t)kvh * GD + lr * 8;
     const int ldw = a.hq * D;
+    // Issue order = arrival order (vector memory returns in order): first the few L2-resident bytes the new token's
+    // q/k/v need, then the cached K/V rows, last the W_o slice that is only consumed at the very end.  (The first
+    // version issued W_o and K/V first: the q/k/v row then arrived behind ~1.4 KiB per lane of HBM traffic and the
+    // norm / RoPE work started 2.9 us into the workgroup - in-kernel stamps, tools/phase_stamps.py.)  In a dual chain
+    // q/k/v do not exist yet when the workgroup starts: the streams go first, then the wait, then the row.
+    const size_t head_off = (((size_t)b * a.hkv + kvh) * a.max_seq) * D;
     uint4 pre[PRE];
+    KVBatch<U0> kb0;
+    NewTokenRaw<G> raw;
+    if constexpr (!DUAL) {
+        new_token_load<D, G, false>(a, b, kvh, lane, raw);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // first KV batch: U0 position-groups per wave = positions [0, U0*NWV*PPW); addresses do not depend on
+    // the context length (clamped), so these loads share the round trip of everything else in this kernel
+    kv_issue<D, U0, NWV>(kb0, a.kcache + head_off, a.vcache + head_off, wid * PPW, a.max_seq - 1, lane);
 #pragma unroll
     for (int p = 0; p < PRE; ++p)  // unconditional (clamped) so nothing waits on these until the GEMV
         pre[p] = load_nt16(wbase + (size_t)(r0 + min(p, npass - 1) * RPP + rip) * ldw);
-
-    // first KV batch: U0 position-groups per wave = positions [0, U0*NWV*PPW); addresses do not depend on
-    // the context length (clamped), so these loads share the round trip of everything else in this kernel
-    const size_t head_off = (((size_t)b * a.hkv + kvh) * a.max_seq) * D;
-    KVBatch<U0> kb0;
-    kv_issue<D, U0, NWV>(kb0, a.kcache + head_off, a.vcache + head_off, wid * PPW, a.max_seq - 1, lane);
-    const int pos = a.positions[b];
-    if constexpr (DUAL) dep_wait(a.dep);   // W_o slice and the cached K/V rows are in flight; q/k/v of this step come from the qkv kernel
+    __builtin_amdgcn_sched_barrier(0);
+    const int pos = load_uniform_i32(a.positions + b);     // scalar path: not queued behind the 50-odd vector loads above
+    tls.phase(0);
+    if constexpr (DUAL) {
+        dep_wait(a.dep);
+        new_token_load<D, G, true>(a, b, kvh, lane, raw);
+    }
     NewToken<D, G> t;
-    prepare_new_token<D, G, DUAL>(a, b, kvh, pos, lane, t);
-    if (blockIdx.x == 0 && pos < a.max_seq && wid == 0 && lane < LPR) {
+    new_token_finish<D, G>(a, lane, raw, t);
+    if (rb == 0 && pos < a.max_seq && wid == 0 && lane < LPR) {
         *reinterpret_cast<uint4*>(a.kcache + head_off + (size_t)pos * D + sub * 8) = t.kbits;
         *reinterpret_cast<uint4*>(a.vcache + head_off + (size_t)pos * D + sub * 8) = t.vbits;
     }
+    tls.phase(1);
     DecodeState<G> st;
     st.init();
     const int c1 = min(pos, a.max_seq);
-    kv_consume<D, G, U0, NWV>(kb0, wid * PPW, c1, t.qf, lane, st);
+    kv_consume<D, G, U0, NWV>(kb0, wid * PPW, c1, t.qb, lane, st);
     if (c1 > U0 * NWV * PPW)
-        decode_walk_trips<D, G, 8, NWV>(a.kcache + head_off, a.vcache + head_off, U0 * NWV * PPW, c1, t.qf, lane, wid, st);
+        decode_walk_trips<D, G, 8, NWV>(a.kcache + head_off, a.vcache + head_off, U0 * NWV * PPW, c1, t.qb, lane, wid, st);
     if (wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
+    tls.phase(2);
     decode_block_merge_lds<D, G, NWV>(st, lds, attn, lane, wid);
+    tls.phase(3);
 
     float xf[8];
     {
@@ -780,6 +860,7 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a, unsigned lo
         acc = group_sum<LPW>(acc);
         if (lr == 0) st_act(outp + row, acc, DUAL);
     }
+    tls.phase(4);
     if constexpr (DUAL) dep_signal(a.dep);
     tls.end();
 }
@@ -1027,6 +1108,7 @@ struct Engine {
     // dual-chain step (engine_common.cuh): arrival counters [4 L][DEP_SHARDS x DEP_STRIDE], the epoch word, the error word,
     // and the second capture branch
     unsigned *dep_cnt = nullptr, *dep_epoch = nullptr, *dep_err = nullptr;
+    bool gateup_r4 = false;         // PGK_GATEUP_R4=1: 4 rows per wave in the batch-1 gate/up GEMV (half the workgroups)
     bool dual_ok = false;           // PGK_DUAL_CHAIN=1 and the shapes suit it (opt-in: measured no faster)
     hipStream_t st2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -1153,7 +1235,7 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
     }
     const bool inmerge = !fused && !direct && e->merge_cnt != nullptr;
     if (inmerge) { a.merge_counter = e->merge_cnt + (size_t)b0 * c.num_kv_heads; a.attn_merged = e->attnv + (size_t)b0 * c.num_heads * D; }
-    dim3 grid = fused ? dim3(c.hidden_size / e->oproj_rows, c.num_kv_heads, m) : dim3(a.nsplit, c.num_kv_heads, m);
+    dim3 grid = fused ? dim3((c.hidden_size / e->oproj_rows) * c.num_kv_heads, 1, m) : dim3(a.nsplit, c.num_kv_heads, m);
     if (dep && fused) a.dep = *dep;
     g_last_grid = (int)(grid.x * grid.y * grid.z);
     hipError_t he = hipSuccess;
@@ -1284,7 +1366,7 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
                 a.dep = wire();
                 // dual chain: 4 rows per wave (half the workgroups, same per-row arithmetic) so that this kernel, spinning on
                 // every CU, still leaves the 256-register slots the attention kernel's workgroups need
-                if (dual) { if (pgk_status r = launch_fused<WT, XT, M, 4, PRO_NORM_SUM, EPI_SWIGLU>(a, I, sA)) return r; }
+                if (dual || e->gateup_r4) { if (pgk_status r = launch_fused<WT, XT, M, 4, PRO_NORM_SUM, EPI_SWIGLU>(a, I, sA)) return r; }
                 else if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM_SUM, EPI_SWIGLU>(a, I, sA)) return r;
                 launched();
                 mlp_in = h2;
@@ -1566,6 +1648,7 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         const int nq = e->qkv_dim();
         const int r_qkv = nq >= 4096 ? 4 : (nq >= 2048 ? 2 : 1), r_gu = 4;
         const int r_dn = c.hidden_size >= 4096 ? 4 : (c.hidden_size >= 2048 ? 2 : 1);
+        if (const char* g4 = getenv("PGK_GATEUP_R4")) e->gateup_r4 = atoi(g4) == 1;
         const char* ed = getenv("PGK_DUAL_CHAIN");
         e->dual_ok = (ed && atoi(ed) == 1) && e->fused_attn && c.weight_format == 0 && c_ok(c.hidden_size, r_qkv) && c_ok(c.hidden_size, r_gu) &&
                      c_ok(c.intermediate_size, r_dn);
@@ -1882,6 +1965,26 @@ pgk_status pgk_engine_timeline(pgk_engine eh, int batch, int warm, uint64_t* h_o
                 agg[4 * i] = s0; agg[4 * i + 1] = s1; agg[4 * i + 2] = e0; agg[4 * i + 3] = e1;
                 if (s0 < origin) origin = s0;
             }
+#ifdef PGK_PHASE_STAMPS
+            {
+                double sum[KC_COUNT][8] = {}, cnt[KC_COUNT][8] = {}, dur[KC_COUNT] = {};
+                for (int i = 0; i < n; ++i) {
+                    const int cls = probe.info[i].cls, nwg = probe.info[i].nwg;
+                    if (cls < 0 || cls >= KC_COUNT || nwg > 256) continue;
+                    for (int w = 0; w < nwg; ++w) {
+                        const unsigned long long t0 = host[((size_t)i * TL_MAXWG + w) * 2], t1 = host[((size_t)i * TL_MAXWG + w) * 2 + 1];
+                        dur[cls] += (double)(t1 - t0);
+                        for (int k = 0; k < 8; ++k) {
+                            const unsigned long long v = host[((size_t)i * TL_MAXWG + 256 + 4 * w) * 2 + k];
+                            if (v) { sum[cls][k] += (double)(v - t0); cnt[cls][k] += 1; }
+                        }
+                    }
+                }
+                for (int cls = 0; cls < KC_COUNT; ++cls)
+                    for (int k = 0; k < 8; ++k)
+                        if (cnt[cls][k] > 0) fprintf(stderr, "phase stamps: class %d phase %d at %.2f us after its workgroup's start (n=%.0f)\n", cls, k, sum[cls][k] / cnt[cls][k] / 100.0, cnt[cls][k]);
+            }
+#endif
             *n_launches = n < max_launches ? n : max_launches;
             for (int i = 0; i < *n_launches; ++i) {
                 h_out[6 * i] = (uint64_t)probe.info[i].cls;

@@ -80,6 +80,16 @@ struct TLStamp {
     __device__ __forceinline__ explicit TLStamp(unsigned long long* tl) : p(tl), t0(0) {
         if (p) t0 = __builtin_amdgcn_s_memrealtime();
     }
+    // -DPGK_PHASE_STAMPS diagnostic builds: up to 8 phase stamps per workgroup (grids <= 256 workgroups), parked in the
+    // launch's unused slots [256 + 4 wg, ...); pgk_engine_timeline prints their means per kernel class to stderr
+    __device__ __forceinline__ void phase(int i) const {
+#ifdef PGK_PHASE_STAMPS
+        if (p && threadIdx.x == 0) {
+            const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            if (wg < 256u) p[2 * (256 + 4 * wg) + i] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
+    }
     __device__ __forceinline__ void end() const {
         if (p) {
             __syncthreads();

@@ -143,6 +143,17 @@ template <int LANES> __device__ __forceinline__ float xor_half(float v) {
     else return __shfl_xor(v, LANES / 2, 64);
 }
 
+// One dword through the SCALAR cache, waited for on the spot.  For wave-uniform device state (a sequence's position) that
+// hipcc would otherwise fetch with a vector load - possible aliasing with the kernel's own stores keeps it off the scalar
+// path - and that a vector load would queue BEHIND every weight / cache load already in flight (vector memory returns in
+// order): with the scalar load the value is there ~1 us earlier and nothing else is held up by waiting for it.
+// The memory must not be written by this launch.
+__device__ __forceinline__ int load_uniform_i32(const int32_t* p) {
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
 // Block-wide sum for blocks of up to 1024 threads (16 waves); `scratch` holds >= 16 floats.
 // Every thread gets the result.  Two barriers.
 __device__ __forceinline__ float block_sum(float v, float* scratch) {

@@ -12,6 +12,19 @@
 
 #include "pgk_device.cuh"
 
+// diagnostic builds (-DPGK_PHASE_STAMPS): stamps inside the walk, parked like TLStamp::phase (engine_common.cuh)
+#ifdef PGK_PHASE_STAMPS
+static __device__ unsigned long long* g_phase_tl;
+#define PGK_PHASE(i)                                                                                              \
+    do {                                                                                                          \
+        unsigned long long* p_ = g_phase_tl;                                                                      \
+        const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                      \
+        if (p_ && threadIdx.x == 0 && wg_ < 256u) p_[2 * (256 + 4 * wg_) + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define PGK_PHASE(i)
+#endif
+
 namespace pgk {
 
 template <class T> struct KVLoad;
@@ -160,6 +173,7 @@ __device__ __forceinline__ void kv_consume(const KVBatch<U>& kb, int p0, int c1,
             }
         }
     }
+    PGK_PHASE(5);
     float mx[G], alpha[G], lsum[G];
     bool any[G];
 #pragma unroll
@@ -173,6 +187,7 @@ __device__ __forceinline__ void kv_consume(const KVBatch<U>& kb, int p0, int c1,
 #pragma unroll
         for (int j = 0; j < 8; ++j) st.o[g][j] *= alpha[g];
     }
+    PGK_PHASE(6);
 #pragma unroll
     for (int u = 0; u < U; u += 2) {
         if (p0 + u * STRIDE < c1) {                         // wave-uniform

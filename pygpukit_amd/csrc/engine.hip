@@ -781,6 +781,10 @@ __global__ void attn_merge_kernel(const float* part, float* attn, int hq, int ns
 template <int D, int G, bool DUAL = false>
 __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a, unsigned long long* tl) {
     const TLStamp tls(tl);
+#ifdef PGK_PHASE_STAMPS
+    if (threadIdx.x == 0) g_phase_tl = tl;      // same value from every workgroup of the launch
+    __syncthreads();
+#endif
     constexpr int NWV = 4;   // 8 waves measured slower: the kernel is issue-bound per SIMD, not per wave
     constexpr int LPR = D / 8, PPW = 64 / LPR, RS = D + 2;
     constexpr int GD = G * D, LPW = GD / 8;          // lanes covering one W_o row slice

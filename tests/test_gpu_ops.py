@@ -571,6 +571,46 @@ def test_gemm256_fp8_matches_oracle_and_128_tile_kernel(shape, monkeypatch):
     assert rel_err(c256, c128) < 3e-3
 
 
+CONFIG5_GEMMS = [(4096, 6144, 4096), (4096, 28672, 4096), (4096, 4096, 14336)]     # qkv, gate_up, down of Llama-3-8B at S = 4096
+
+
+@pytest.mark.parametrize("shape", CONFIG5_GEMMS)
+def test_config5_shape_gemms_fp8a8_and_w8a16_vs_oracle(shape, monkeypatch):
+    """BASELINE config 5's projection GEMMs at their REAL shapes (M = 4096 rows of Llama-3-8B), both the 256-tile LDS-DMA
+    kernels and the 128-tile ones (PGK_GEMM256 = 1 / 0), fp8 x fp8 (activations quantised per row and 128 k) and w8a16:
+      * against the oracle evaluated on the SAME codes and scales (what is left is accumulation order and the bf16 store):
+        3e-3 for fp8 x fp8, 1e-2 for w8a16 (bf16 activations against fp32 ones in the oracle);
+      * against the product of the unquantised operands: BASELINE's 5e-2 fp8 bar, per GEMM.
+    Operands are quantised on the device (value-identical to the oracle's quantisers: test_quantize_fp8_* above); the
+    oracle is evaluated on every 16th output row (a 4096 x 28672 x 4096 product in float64 is not a unit test)."""
+    M, N, K = shape
+    rng = np.random.default_rng(41)
+    a = (rng.standard_normal((M, K), dtype=np.float32) * rng.uniform(0.2, 3.0, (M, 1)).astype(np.float32))
+    w = rng.standard_normal((N, K), dtype=np.float32) * np.float32(0.02)
+    a16, w16 = dev(a, "bfloat16"), dev(w, "bfloat16")
+    a = O.bf16_round(a)
+    rows = np.arange(0, M, 16)
+    exact = a[rows] @ O.bf16_round(w).T                                   # the unquantised product (bf16-valued operands)
+    del w
+    w8, sw = ops.quantize_fp8_blocks(w16)
+    a8, sa = ops.quantize_fp8_rows(a16)
+    wdq = O.dequantize_fp8_e4m3_block(w8.to_numpy(), sw.to_numpy())     # [N, K] fp32: the values both GEMMs multiply
+    tab = O.fp8_e4m3_table()
+    adq = tab[a8.to_numpy()[rows]].astype(np.float32) * np.repeat(sa.to_numpy()[rows], 128, axis=1)
+    ref_a8 = adq @ wdq.T
+    ref_w8 = a[rows] @ wdq.T
+    for tile in ("1", "0"):
+        monkeypatch.setenv("PGK_GEMM256", tile)
+        c = host(ops.gemm_fp8_fp8_blockwise_nt(a8, w8, sa, sw))
+        assert np.isfinite(c).all()
+        assert rel_err(c[rows], ref_a8) < 3e-3, (tile, rel_err(c[rows], ref_a8))
+        assert rel_err(c[rows], exact) < 5e-2, (tile, rel_err(c[rows], exact))
+        c = host(ops.w8a16_gemm_nk(a16, w8, sw))
+        assert np.isfinite(c).all()
+        assert rel_err(c[rows], ref_w8) < 1e-2, (tile, rel_err(c[rows], ref_w8))
+        assert rel_err(c[rows], exact) < 5e-2, (tile, rel_err(c[rows], exact))
+
+
 def test_gemm_fp8_exact_integers_and_asymmetric_operand():
     """Small-integer operands with unit scales are exact in e4m3 and in fp32: the result must be bit-exact, which
     pins the A/B lane->k pairing and the C row/col map (an asymmetric W catches a transposed store)."""

@@ -478,7 +478,8 @@ struct AttnArgs {
     int* merge_counter;   // split path, in-kernel merge: [B][Hkv] arrival counters (null: separate attn_merge_kernel)
     float* attn_merged;   //   ... and where the last-arriving workgroup of a kv head writes the merged output [B][Hq][D]
     // fused o_proj path
-    const bf16* w_o;      // [H][Hq*D]
+    const bf16* w_o;      // [H][Hq*D] (fp8 codes on the merged o_proj path with fp8 weights)
+    const bf16* w_o_scale; // fp8 W_o: [H/128][Hq*D/128] block scales
     int H, rows_per_block;
     float* opart;         // [B][Hkv][H]
     bf16* attn_direct16;  // whole-context variant: bf16 output instead of attn_direct (batched MFMA o_proj reads it)
@@ -656,20 +657,35 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
         tls.end();
         return;
     }
+    // Slices are cut by ABSOLUTE position (slice s = cache rows [s * chunk, (s + 1) * chunk), chunk from the cache length):
+    // no address depends on the context length, so the new token's q/k/v and the slice's first 128 K/V rows are requested
+    // before the position is even known (clamped addresses; masked later).  Before, the walk started one scalar and one
+    // vector round trip later (position -> slice bounds -> addresses).  Slices beyond the context write empty records.
+    constexpr int U1 = 8;
+    const int chunk = decode_chunk_len(a.max_seq, a.nsplit, 4 * PPW);
+    const int c0 = (int)blockIdx.x * chunk;
+    NewTokenRaw<G> raw;
+    new_token_load<D, G, false>(a, b, kvh, lane, raw);
+    __builtin_amdgcn_sched_barrier(0);
+    KVBatch<U1> kb0;
+    kv_issue<D, U1, 4>(kb0, a.kcache + head_off, a.vcache + head_off, c0 + wid * PPW, a.max_seq - 1, lane);
+    __builtin_amdgcn_sched_barrier(0);
     const int pos = load_uniform_i32(a.positions + b);   // scalar path (pgk_device.cuh): not queued behind the vector loads in flight
     const int ctx = min(pos + 1, a.max_seq);
     NewToken<D, G> t;
-    prepare_new_token<D, G>(a, b, kvh, pos, lane, t);
-    const int chunk = decode_chunk_len(ctx, a.nsplit, 4 * PPW);
-    const int c0 = min((int)blockIdx.x * chunk, ctx), c1 = min(c0 + chunk, ctx);
-    const bool owns_new = (pos < a.max_seq) && (pos >= c0) && (pos < c1);
+    new_token_finish<D, G>(a, lane, raw, t);
+    const int c1 = min(c0 + chunk, ctx);
+    const bool owns_new = (pos < a.max_seq) && (pos >= c0) && (pos < c0 + chunk);
     if (owns_new && wid == 0 && lane < LPR && a.g_off == 0) {
         *reinterpret_cast<uint4*>(a.kcache + head_off + (size_t)pos * D + sub * 8) = t.kbits;
         *reinterpret_cast<uint4*>(a.vcache + head_off + (size_t)pos * D + sub * 8) = t.vbits;
     }
     DecodeState<G> st;
     st.init();
-    decode_walk_trips<D, G>(a.kcache + head_off, a.vcache + head_off, c0, owns_new ? min(c1, pos) : c1, t.qb, lane, wid, st);
+    const int cend = owns_new ? min(c1, pos) : c1;       // cached rows of this slice; the new token's row is folded from registers
+    kv_consume<D, G, U1, 4>(kb0, c0 + wid * PPW, cend, t.qb, lane, st);
+    if (cend > c0 + U1 * 4 * PPW)
+        decode_walk_trips<D, G>(a.kcache + head_off, a.vcache + head_off, c0 + U1 * 4 * PPW, cend, t.qb, lane, wid, st);
     if (owns_new && wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
     if constexpr (DIRECT) {
         // this workgroup saw the whole context: normalise here and skip the merge launch
@@ -866,6 +882,106 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a, unsigned lo
     }
     tls.phase(4);
     if constexpr (DUAL) dep_signal(a.dep);
+    tls.end();
+}
+
+// long-context path, steps 2 + 3 in ONE launch: merge the split-KV records of a kv head's G query heads (the arithmetic
+// of attn_merge_kernel, same order) and multiply the result with this workgroup's slice of W_o.  Grid as attn_oproj_kernel
+// ((H / rows_per_block) * Hkv, kv head fastest: XCD-aware), output the same per-kv-head partial vectors, which the
+// gate/up kernel's PRO_NORM_SUM prologue adds to the residual stream.  Replaces attn_merge_kernel + the o_proj GEMV:
+// one launch and one dependent-kernel gap less per layer (context 2048, w8a16: the pair took 1.95 + 1.3 + 1.74 us of
+// every 23.8 us layer; profiles/r02_config3_timeline.json).  W_o bf16 or fp8 (16 codes per lane, block scale in registers).
+template <int D, int G, bool FP8>
+__global__ __launch_bounds__(256) void attn_merge_oproj_kernel(AttnArgs a, unsigned long long* tl) {
+    const TLStamp tls(tl);
+    constexpr int RS = D + 2, GD = G * D;
+    constexpr int NWT = FP8 ? 16 : 8;                // weights per 16-byte load
+    constexpr int LPW = GD / NWT;                    // lanes covering one W_o row slice
+    constexpr int RPP = 256 / LPW;                   // rows per pass of the workgroup
+    constexpr int PRE = 4;
+    static_assert(LPW <= 64 && 256 % LPW == 0, "row slice must fit a wave");
+    __shared__ float w_s[G][64];
+    __shared__ float inv_l[G];
+    __shared__ __attribute__((aligned(16))) float attn[GD];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kvh = blockIdx.x % a.hkv, rb = blockIdx.x / a.hkv, b = blockIdx.z;
+    const int r0 = rb * a.rows_per_block;
+    const int lr = threadIdx.x % LPW, rip = threadIdx.x / LPW;
+    const int npass = a.rows_per_block / RPP;
+    const int ldw = a.hq * D;
+    const int col0 = kvh * GD + lr * NWT;
+    const char* wbase = reinterpret_cast<const char*>(a.w_o) + (size_t)col0 * (FP8 ? 1 : 2);
+    const size_t row_bytes = (size_t)ldw * (FP8 ? 1 : 2);
+    // the record words first (L2, written by the launch before), then the W_o stream: arrival order = issue order
+    const float* hrecs = a.part + ((size_t)b * a.hq + (size_t)kvh * G) * a.nsplit * RS;
+    float m = -INFINITY, l = 0.f;
+    if (wid < G) {
+        const int sc = min(lane, a.nsplit - 1);
+        m = hrecs[((size_t)wid * a.nsplit + sc) * RS];
+        l = hrecs[((size_t)wid * a.nsplit + sc) * RS + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 pre[PRE];
+    float psc[PRE];
+#pragma unroll
+    for (int p = 0; p < PRE; ++p) {
+        const int row = r0 + min(p, npass - 1) * RPP + rip;
+        pre[p] = load_nt16(wbase + (size_t)row * row_bytes);
+        if constexpr (FP8) psc[p] = to_f(a.w_o_scale[(size_t)(row >> 7) * (ldw >> 7) + (col0 >> 7)]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (wid < G) {
+        if (lane >= a.nsplit) { m = -INFINITY; l = 0.f; }
+        const float mx = wave_max(m);
+        const float w = (m == -INFINITY) ? 0.f : __expf(m - mx);
+        const float tot = wave_sum(w * l);
+        w_s[wid][lane] = w;
+        if (lane == 0) inv_l[wid] = tot > 0.f ? 1.0f / tot : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < GD; e += 256) {
+        const int g = e / D, d = e % D;
+        const float* recs = hrecs + (size_t)g * a.nsplit * RS;
+        float o = 0.f;
+        int s = 0;
+        for (; s + 8 <= a.nsplit; s += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = recs[(size_t)(s + u) * RS + 2 + d];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o = fmaf(w_s[g][s + u], v[u], o);
+        }
+        for (; s < a.nsplit; ++s) o = fmaf(w_s[g][s], recs[(size_t)s * RS + 2 + d], o);
+        attn[e] = o * inv_l[g];
+    }
+    __syncthreads();
+    float xf[NWT];
+#pragma unroll
+    for (int i = 0; i < NWT / 4; ++i) {
+        const float4 u = *reinterpret_cast<const float4*>(attn + lr * NWT + 4 * i);
+        xf[4 * i] = u.x; xf[4 * i + 1] = u.y; xf[4 * i + 2] = u.z; xf[4 * i + 3] = u.w;
+    }
+    float* outp = a.opart + ((size_t)b * a.hkv + kvh) * a.H;
+    for (int p = 0; p < npass; ++p) {
+        const int row = r0 + p * RPP + rip;
+        uint4 w;
+        float sc = 1.f;
+        if (p < PRE) {
+            w = pre[p < PRE ? p : 0];
+            if constexpr (FP8) sc = psc[p < PRE ? p : 0];
+        } else {
+            w = load_nt16(wbase + (size_t)row * row_bytes);
+            if constexpr (FP8) sc = to_f(a.w_o_scale[(size_t)(row >> 7) * (ldw >> 7) + (col0 >> 7)]);
+        }
+        float wf[NWT];
+        if constexpr (FP8) WTraits<fp8e4m3>::decode(w, wf);
+        else WTraits<bf16>::decode(w, wf);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NWT; ++j) acc = fmaf(wf[j], xf[j], acc);
+        acc = group_sum<LPW>(acc * sc);      // scale per lane: a row slice of G*D columns may span several 128-column scale blocks
+        if (lr == 0) outp[row] = acc;
+    }
     tls.end();
 }
 
@@ -1098,6 +1214,8 @@ struct Engine {
     static constexpr int skip_attn = 0;
 #endif
     bool fused_attn = false;   // attn + o_proj in one kernel (short contexts, bf16 W_o)
+    bool merged_oproj = false; // long contexts / fp8 W_o, one or two sequences: split-KV merge + o_proj in one kernel (PGK_MERGED_OPROJ=0: merge kernel + GEMV)
+    int moproj_rows = 32;
     int oproj_rows = 32;       // W_o rows per workgroup on the fused path
     // device state
     bf16 *kcache = nullptr, *vcache = nullptr;
@@ -1204,7 +1322,7 @@ static int gqa_chunks(int G) {
 
 template <int D>
 static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, hipStream_t st, bool direct_bf16 = false,
-                              const DepArgs* dep = nullptr) {
+                              const DepArgs* dep = nullptr, bool merged = false) {
     const auto& c = e->cfg;
     const auto& L = e->layers[layer];
     const int G = c.num_heads / c.num_kv_heads;
@@ -1226,8 +1344,10 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
     // the workspace was sized for (e->nsplit: ~64 positions per slice at the full cache length)
     // (batches stream enough KV bytes to want two workgroups per CU: measured 22.1 vs 24.6 us at 8 x 2048 positions)
     int ns = e->cu_count * (e->attn_waves > 0 ? e->attn_waves : (m >= 4 ? 2 : 1)) / (c.num_kv_heads * m);
-    a.nsplit = ns < 1 ? 1 : (ns > e->nsplit ? e->nsplit : ns);
-    a.w_o = (const bf16*)L.w_o; a.H = c.hidden_size; a.rows_per_block = e->oproj_rows;
+    ns = ns < 1 ? 1 : (ns > e->nsplit ? e->nsplit : ns);
+    // slices are cut by absolute position in whole position-group steps: launch only as many as the cache length needs
+    a.nsplit = ceil_div(c.max_seq_len, decode_chunk_len(c.max_seq_len, ns, 4 * (64 / (D / 8))));
+    a.w_o = (const bf16*)L.w_o; a.w_o_scale = (const bf16*)L.s_o; a.H = c.hidden_size; a.rows_per_block = e->oproj_rows;
     a.opart = e->opart ? e->opart + (size_t)b0 * c.num_kv_heads * c.hidden_size : nullptr;
     // batches at short context: one workgroup per (sequence, kv head) walks the whole context and writes the
     // normalised output itself - Hkv * m workgroups, and the merge launch disappears
@@ -1273,7 +1393,22 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
 #undef PGK_ATTN
     PGK_CHECK_HIP(he);
     }
-    if (!fused && !direct && !inmerge) {
+    if (merged) {
+        // split-KV merge + o_proj partial products in one launch (attn_merge_oproj_kernel)
+        PGK_REQUIRE(!fused && !direct && !inmerge && (G == 1 || G == 2 || G == 4), "engine: merged o_proj on an unsupported attention path");
+        mark(KC_OPROJ);
+        a.rows_per_block = e->moproj_rows;
+        const dim3 g2((c.hidden_size / e->moproj_rows) * c.num_kv_heads, 1, m);
+        const bool f8 = c.weight_format != 0;
+#define PGK_MO(GG)                                                                                             \
+    case GG:                                                                                                   \
+        he = f8 ? launch_k(attn_merge_oproj_kernel<D, GG, true>, g2, dim3(256), 0, st, a)                       \
+                : launch_k(attn_merge_oproj_kernel<D, GG, false>, g2, dim3(256), 0, st, a);                     \
+        break;
+        switch (G) { PGK_MO(1) PGK_MO(2) PGK_MO(4) default: break; }
+#undef PGK_MO
+        PGK_CHECK_HIP(he);
+    } else if (!fused && !direct && !inmerge) {
         PGK_CHECK_HIP(launch_k(attn_merge_kernel<D>, dim3(c.num_heads, m), dim3(D), 0, st, (const float*)a.part,
                                e->attnv + (size_t)b0 * c.num_heads * D, (int)c.num_heads, (int)a.nsplit));
     }
@@ -1306,6 +1441,9 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
     // two sequences at short context, wasteful for a batch - batches take the split-KV path.
     const bool fused = e->fused_attn && M <= 2;
     dual = dual && fused && !e->skip_attn;
+    // long contexts (or fp8 W_o): split-KV slices, then merge + o_proj partials in one launch; the gate/up prologue adds them
+    const bool merged = !fused && M <= 2 && e->merged_oproj && !e->merge_cnt;
+    const bool partials = fused || merged;
     const bool two = dual && st2 && st2 != st;
     hipStream_t sA = st, sB = two ? st2 : st;
     if (two) {   // fork: the second branch starts behind everything already enqueued on the first
@@ -1341,12 +1479,13 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
         // 2. attention (QK-norm, RoPE, KV write fused; on the fused path also the o_proj partial products)
         if (!e->skip_attn) {
             const DepArgs d = wire();
-            if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, fused, sB, false, &d)) return r; }
-            else { if (pgk_status r = launch_attn<64>(e, l, b0, M, fused, sB, false, &d)) return r; }
+            if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, fused, sB, false, &d, merged)) return r; }
+            else { if (pgk_status r = launch_attn<64>(e, l, b0, M, fused, sB, false, &d, merged)) return r; }
             launched();
         }
         const float* mlp_in = h;
-        if (!fused) {
+        if (merged) *launches += 1;          // the merge + o_proj launch
+        if (!partials) {
             mark(KC_OPROJ);
             // 3. h += Wo . attn   (attn = merged split-KV records, written by attn_merge_kernel)
             a = FusedArgs{};
@@ -1364,8 +1503,8 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
         a.h = h; a.gamma = (const bf16*)L.mlp_norm; a.eps = c.norm_eps;
         a.out = e->act + (size_t)b0 * I; a.ld_out = I;
         bool done_gateup = false;
-        if constexpr (M <= 2) {   // the fused path only ever runs for one or two sequences per chunk
-            if (fused) {
+        if constexpr (M <= 2) {   // per-kv-head o_proj partials only ever exist for one or two sequences per chunk
+            if (partials) {
                 a.part = e->opart + (size_t)b0 * c.num_kv_heads * H; a.nsplit = c.num_kv_heads; a.h_out = h2;
                 a.dep = wire();
                 // dual chain: 4 rows per wave (half the workgroups, same per-row arithmetic) so that this kernel, spinning on
@@ -1583,6 +1722,15 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         const bool want = env ? atoi(env) != 0 : true;
         e->fused_attn = want && tiles && c.weight_format == 0 && c.max_seq_len <= 512 && (G == 1 || G == 2 || G == 4);
         e->oproj_rows = rows;
+        // merged o_proj (long contexts, fp8 W_o): same slicing rule with 16 codes per lane for fp8
+        const int nwt = c.weight_format != 0 ? 16 : 8, lpw = gd / nwt, rpp2 = lpw > 0 ? 256 / lpw : 256;
+        int rows2 = c.hidden_size / 32;
+        while (rows2 > 4 * rpp2 && rows2 % 2 == 0) rows2 /= 2;
+        while (rows2 < rpp2) rows2 *= 2;
+        const char* emo = getenv("PGK_MERGED_OPROJ");
+        e->merged_oproj = !(emo && atoi(emo) == 0) && (G == 1 || G == 2 || G == 4) && lpw >= 8 && lpw <= 64 && 256 % lpw == 0 &&
+                          rows2 % rpp2 == 0 && c.hidden_size % rows2 == 0 && (c.weight_format == 0 || (gd % 128 == 0 || 128 % gd == 0));
+        e->moproj_rows = rows2;
     }
     const int B = c.max_batch, H = c.hidden_size, D = c.head_dim;
     pgk_status r = PGK_OK;

@@ -1197,6 +1197,7 @@ struct Engine {
     std::vector<pgk_layer_weights_t> layers;
     int nsplit = 1, lm_blocks = 1, lm_cap = 1, log_cap = 4096;
     bool batched_mfma = true;   // chunks of 3 and 5..16 sequences use engine_batched.cuh (PGK_BATCHED_MFMA=0: GEMV kernels only, =2: from 3 up, =3: from 9 up)
+    bool tiled_norm_fused = false;  // PGK_TILED_NORM_FUSED=1: fold the RMSNorms of the 17..64-sequence path into their neighbours (measured slower: DESIGN.md)
     int batched_min = 5, batched_max = 64;   // PGK_BATCHED_MAX=16: chunks of at most 16 sequences (one weight pass per chunk), the A/B switch of the tiled kernels
     int cu_count = 256, attn_waves = 0;   // attn_waves: PGK_ATTN_WAVES override of the workgroups-per-CU target (0 = by batch)
     int* merge_cnt = nullptr;      // PGK_ATTN_INKERNEL_MERGE=1: split-KV attention merges inside the launch (last arriver); default: merge kernel
@@ -1222,7 +1223,8 @@ struct Engine {
     float *rope_cos = nullptr, *rope_sin = nullptr, *cur_cos = nullptr, *cur_sin = nullptr;
     int32_t *tokens = nullptr, *positions = nullptr, *token_log = nullptr, *step_counter = nullptr;
     bf16 *act16 = nullptr, *attnv16 = nullptr;   // batched MFMA path: bf16 hand-off of SwiGLU output and attention output
-    bf16* x16 = nullptr;                         // 17..64 sequences: RMSNorm'ed rows in bf16 (norm_rows_bf16)
+    bf16* x16 = nullptr;                         // 17..64 sequences: the next RMSNorm's input rows in bf16 (layer 0: normalised by norm_rows_bf16; then un-normalised, written by o_proj / down)
+    float* ss_part = nullptr;                    // ... and its statistic: per-workgroup sums of squares [64][1024]
     float *h = nullptr, *h2 = nullptr, *qkv = nullptr, *part = nullptr, *opart = nullptr, *attnv = nullptr, *act = nullptr, *logits = nullptr,
           *amax_val = nullptr;
     int* amax_idx = nullptr;
@@ -1572,6 +1574,11 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
     bf16* x16 = e->x16 + (size_t)b0 * H;
     const bool tiled = M > 16;
     const bool direct = e->attn_direct_ok && M >= 3;
+    // tiled path, opt-in experiment: RMSNorm folded into its neighbours (FusedArgs: hb16_out / ss_out on the producer of the
+    // residual stream, ss_in on the consumer); default: one small norm_rows_bf16 launch per RMSNorm, which measured faster
+    // (batch 64: 1.88-1.95 ms per step against 2.07-2.09 - every consumer workgroup re-derives the 64 row statistics)
+    const bool nf = tiled && e->tiled_norm_fused;
+    const int ss_n = batched_tiled_groups(H, EPI_RESID);
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& L = e->layers[l];
         FusedArgs a{};
@@ -1580,7 +1587,8 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
         a.h = h; a.gamma = (const bf16*)L.attn_norm; a.eps = c.norm_eps;
         a.out = e->qkv + (size_t)b0 * NQKV; a.ld_out = NQKV;
         if (tiled) {
-            if (pgk_status r = norm_rows_bf16(h, a.gamma, x16, M, H, c.norm_eps, st)) return r;
+            if (nf && l > 0) { a.ss_in = e->ss_part; a.ss_n = ss_n; }      // x16 / ss_part were left by the previous layer's down_proj
+            else { if (pgk_status r = norm_rows_bf16(h, a.gamma, x16, M, H, c.norm_eps, st)) return r; *launches += 1; }
             a.xin16 = x16;
         }
         if (pgk_status r = batched_proj(FP8, tiled ? PRO_PLAIN : PRO_NORM, EPI_STORE, a, M, st)) return r;
@@ -1598,6 +1606,7 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
             a.xin16 = e->attnv16 + (size_t)b0 * QD;
             *launches += 1;
         }
+        if (nf) { a.hb16_out = x16; a.gamma_next = (const bf16*)L.mlp_norm; a.ss_out = e->ss_part; }
         if (pgk_status r = batched_proj(FP8, PRO_PLAIN, EPI_RESID, a, M, st)) return r;
         mark(KC_GATEUP);
         a = FusedArgs{};
@@ -1606,7 +1615,8 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
         a.out = e->act + (size_t)b0 * I; a.ld_out = I;
         a.out16 = e->act16 + (size_t)b0 * I;        // SiLU(g) * u leaves as bf16: down_proj rounds it to bf16 anyway
         if (tiled) {
-            if (pgk_status r = norm_rows_bf16(h, a.gamma, x16, M, H, c.norm_eps, st)) return r;
+            if (nf) { a.ss_in = e->ss_part; a.ss_n = ss_n; }
+            else { if (pgk_status r = norm_rows_bf16(h, a.gamma, x16, M, H, c.norm_eps, st)) return r; *launches += 1; }
             a.xin16 = x16;
         }
         if (pgk_status r = batched_proj(FP8, tiled ? PRO_PLAIN : PRO_NORM, EPI_SWIGLU, a, M, st)) return r;
@@ -1616,8 +1626,11 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
         a.xin = e->act + (size_t)b0 * I;
         a.xin16 = e->act16 + (size_t)b0 * I;
         a.res = h; a.out = h; a.ld_out = H;
+        if (nf) {
+            if (l + 1 < c.num_layers) { a.hb16_out = x16; a.ss_out = e->ss_part; a.gamma_next = (const bf16*)e->layers[l + 1].attn_norm; }
+        }
         if (pgk_status r = batched_proj(FP8, PRO_PLAIN, EPI_RESID, a, M, st)) return r;
-        *launches += ((direct || e->merge_cnt) ? 5 : 6) + (tiled ? 2 : 0) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;
+        *launches += ((direct || e->merge_cnt) ? 5 : 6) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;
     }
     const int nblk = ceil_div(c.vocab_size, 16) < 2048 ? ceil_div(c.vocab_size, 16) : 2048;
     mark(KC_LMHEAD);
@@ -1627,9 +1640,10 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
     a.out = e->logits + (size_t)b0 * c.vocab_size; a.ld_out = c.vocab_size;
     a.amax_val = e->amax_val + (size_t)b0 * e->lm_cap; a.amax_idx = e->amax_idx + (size_t)b0 * e->lm_cap;
     if (tiled) {
+        // the final norm keeps its launch: 2048 lm_head workgroups re-deriving the row statistic would read 128 MB of partials
         if (pgk_status r = norm_rows_bf16(h, a.gamma, x16, M, H, c.norm_eps, st)) return r;
-        a.xin16 = x16;
         *launches += 1;
+        a.xin16 = x16;
     }
     if (pgk_status r = batched_proj(false, tiled ? PRO_PLAIN : PRO_NORM, EPI_LOGITS, a, M, st, nblk)) return r;
     mark(KC_ARGMAX);
@@ -1754,6 +1768,7 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
     A((void**)&e->act16, (size_t)B * c.intermediate_size * 2, &e->ws_bytes);
     A((void**)&e->attnv16, (size_t)B * c.num_heads * c.head_dim * 2, &e->ws_bytes);
     A((void**)&e->x16, (size_t)B * H * 2, &e->ws_bytes);
+    A((void**)&e->ss_part, (size_t)64 * 1024 * 4, &e->ws_bytes);
     A((void**)&e->attnv, (size_t)B * c.num_heads * D * 4, &e->ws_bytes);
     A((void**)&e->act, (size_t)B * c.intermediate_size * 4, &e->ws_bytes);
     A((void**)&e->logits, (size_t)B * c.vocab_size * 4, &e->ws_bytes);
@@ -1771,6 +1786,7 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         // 17..64 sequences in one weight pass (batched_mt_kernel) need K = 128 S with S instantiated; otherwise chunks of 16
         auto k_tiled = [](int K) { const int s = K / 128; return K % 128 == 0 && (s == 2 || s == 4 || s == 8 || s == 16 || s == 24 || s == 32); };
         e->batched_max = (k_tiled(c.hidden_size) && k_tiled(c.intermediate_size) && k_tiled(c.num_heads * c.head_dim)) ? 64 : 16;
+        if (const char* tn = getenv("PGK_TILED_NORM_FUSED")) e->tiled_norm_fused = atoi(tn) != 0;
         if (const char* em = getenv("PGK_BATCHED_MAX")) { const int v = atoi(em); if (v >= 16 && v < e->batched_max) e->batched_max = v; }
     }
     {

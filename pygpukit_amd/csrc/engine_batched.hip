@@ -61,6 +61,8 @@ __global__ __launch_bounds__(256) void norm_rows_bf16_kernel(const float* h, con
     tls.end();
 }
 
+int batched_tiled_groups(int N, int epi) { return ceil_div(N, mt_rows_per_group(N, epi)); }
+
 pgk_status norm_rows_bf16(const float* h, const bf16* gamma, bf16* x16, int M, int K, float eps, hipStream_t st) {
     PGK_REQUIRE(h && x16 && M >= 1 && K >= 4 && K % 4 == 0, "norm_rows_bf16: bad arguments (M=%d, K=%d)", M, K);
     PGK_CHECK_HIP(launch_k(norm_rows_bf16_kernel, dim3(M), dim3(256), 0, st, h, gamma, x16, K, eps));

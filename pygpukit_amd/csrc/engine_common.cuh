@@ -206,6 +206,15 @@ struct FusedArgs {
     const bf16* xin16;    // PRO_PLAIN: [M][K] bf16, used instead of xin when set
     bf16* out16;          // EPI_SWIGLU: [M][ld_out] bf16, written instead of out when set
     DepArgs dep;          // dual-chain step (GEMV kernels with compile-time K only); all null otherwise
+    // M-tiled batched path (17..64 sequences): RMSNorm without a launch of its own.  A producer of the residual stream
+    // (EPI_RESID) also leaves hb16 = bf16(h_new * gamma_next) and, per workgroup, the sum of squares of its columns of every
+    // row; the consumer multiplies with the UN-normalised hb16 rows and scales its results by
+    // inv[m] = rsqrt(sum over the producer's workgroups / K + eps) - a per-row scalar commutes with the product.
+    bf16* hb16_out;           // EPI_RESID: [M][ld_out]
+    const bf16* gamma_next;   // EPI_RESID: [N]
+    float* ss_out;            // EPI_RESID: [64 rows][1024]: column = the producing workgroup
+    const float* ss_in;       // consumer: the same table (null: the rows in xin16 are already normalised)
+    int ss_n;                 // producer workgroups (<= 1024)
 };
 
 // engine_batched.hip: projections for 3..64 sequences on MFMA.  `pro`/`epi` are the codes above; `fp8` selects e4m3
@@ -213,6 +222,9 @@ struct FusedArgs {
 // PRO_PLAIN with a.xin16 set (rows already normalised to bf16 by norm_rows_bf16) and reads each weight byte ONCE for
 // all M rows.
 pgk_status batched_proj(bool fp8, int pro, int epi, const FusedArgs& a, int M, hipStream_t st, int nblk_logits = 0);
+// workgroups the M-tiled kernel launches for an N-column projection with epilogue `epi` (= the columns of the
+// sum-of-squares table an EPI_RESID producer fills)
+int batched_tiled_groups(int N, int epi);
 // x16[m][:] = bf16(rmsnorm(h[m][:]) * gamma): one workgroup per row
 pgk_status norm_rows_bf16(const float* h, const bf16* gamma, bf16* x16, int M, int K, float eps, hipStream_t st);
 

@@ -633,11 +633,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
         // position share one memory round trip (the split path below learns the position first, then walks:
         // two dependent trips - 9.2 us against 6.x for 8 sequences).
         constexpr int U0 = 12;
+        NewTokenRaw<G> raw;                 // issue order = arrival order: the few L2-resident q/k/v bytes first, then the K/V rows
+        new_token_load<D, G, false>(a, b, kvh, lane, raw);
+        __builtin_amdgcn_sched_barrier(0);
         KVBatch<U0> kb0;
         kv_issue<D, U0, 4>(kb0, a.kcache + head_off, a.vcache + head_off, wid * PPW, a.max_seq - 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
         const int pos = load_uniform_i32(a.positions + b);   // scalar path (pgk_device.cuh): not queued behind the vector loads in flight
         NewToken<D, G> t;
-        prepare_new_token<D, G>(a, b, kvh, pos, lane, t);
+        new_token_finish<D, G>(a, lane, raw, t);
         if (pos < a.max_seq && wid == 0 && lane < LPR && a.g_off == 0) {
             *reinterpret_cast<uint4*>(a.kcache + head_off + (size_t)pos * D + sub * 8) = t.kbits;
             *reinterpret_cast<uint4*>(a.vcache + head_off + (size_t)pos * D + sub * 8) = t.vbits;

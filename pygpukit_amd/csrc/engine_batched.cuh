@@ -271,12 +271,16 @@ __global__ __launch_bounds__(256) void batched_reg_kernel(FusedArgs a, int M, in
             }
         }
     };
-    load_w(blockIdx.x * RPG);                              // in flight before the activations are touched
     const int em = tid >> 4, en = tid & 15;
 
     // ---- activation fragments of this wave's K quarter ----
+    // Issue order = arrival order: the activation rows (L2) are requested BEFORE the weight stream (HBM), so the RMSNorm
+    // statistic, its barrier and the bf16 conversion run while the weights are still in flight (the other way round the
+    // prologue started when the last weight byte had landed - the batch-1 kernels' lesson).
     const float* src = ((PRO == PRO_NORM) ? a.h : a.xin) + (size_t)min(l15, M - 1) * K + kw0 + 8 * q;
     uint4 af[S];
+    constexpr bool HOLD_FIRST = PRO == PRO_NORM && S <= 8;      // raw rows held in registers across the reduction
+    if constexpr (!HOLD_FIRST) load_w(blockIdx.x * RPG);        // (deep K: the rows are re-read after the barrier anyway)
     auto pack8 = [](const float4& u, const float4& v, float inv, const float* g) {
         return make_uint4(pack_bf16x2(u.x * inv * g[0], u.y * inv * g[1]), pack_bf16x2(u.z * inv * g[2], u.w * inv * g[3]),
                           pack_bf16x2(v.x * inv * g[4], v.y * inv * g[5]), pack_bf16x2(v.z * inv * g[6], v.w * inv * g[7]));
@@ -285,11 +289,23 @@ __global__ __launch_bounds__(256) void batched_reg_kernel(FusedArgs a, int M, in
         constexpr bool HOLD = S <= 8;                      // raw rows stay in registers across the reduction
         float4 r0[HOLD ? S : 1], r1[HOLD ? S : 1];
         float ss = 0.f;
+        if constexpr (HOLD) {
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const float4 u = *reinterpret_cast<const float4*>(src + s * 32), v = *reinterpret_cast<const float4*>(src + s * 32 + 4);
-            if constexpr (HOLD) { r0[s] = u; r1[s] = v; }
-            ss += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w + v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            for (int s = 0; s < S; ++s) { r0[s] = *reinterpret_cast<const float4*>(src + s * 32); r1[s] = *reinterpret_cast<const float4*>(src + s * 32 + 4); }
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(blockIdx.x * RPG);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float4 u = r0[s], v = r1[s];
+                ss += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w + v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float4 u = *reinterpret_cast<const float4*>(src + s * 32), v = *reinterpret_cast<const float4*>(src + s * 32 + 4);
+                ss += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w + v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
         }
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);

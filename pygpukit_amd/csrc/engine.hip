@@ -28,6 +28,7 @@
 
 #include "attn_core.cuh"
 #include "engine_common.cuh"
+#include "pkgemm.cuh"
 
 namespace pgk {
 
@@ -1241,6 +1242,11 @@ struct Engine {
     hipStream_t st2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t kv_bytes = 0, ws_bytes = 0;
+    // fragment-major copies of the layer weights for prompts of <= 128 tokens (ops_pkgemm.hip); PGK_PACKED_PREFILL=0: none
+    struct PackedLayer { bf16 *qkv = nullptr, *o = nullptr, *gate_up = nullptr, *down = nullptr; };
+    std::vector<PackedLayer> packed;
+    bool packed_ok = false;
+    size_t packed_bytes = 0;
     // prefill workspace (grown on demand, outside capture)
     void* pf = nullptr;
     size_t pf_bytes = 0;
@@ -1830,6 +1836,34 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
                 e->dual_ok = false;
         }
     }
+    {
+        // Second, fragment-major copy of the bf16 layer weights: what the short-prompt prefill streams (ops_pkgemm.hip).
+        // Costs the layers' bytes again; skipped when that is more than a quarter of the device's free memory.
+        const int QDp = c.num_heads * D, NQ = e->qkv_dim(), I = c.intermediate_size;
+        const char* ep = getenv("PGK_PACKED_PREFILL");
+        const size_t per_layer = ((size_t)NQ * H + (size_t)H * QDp + (size_t)2 * I * H + (size_t)H * I) * 2;
+        size_t free_b = 0, total_b = 0;
+        const bool fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && per_layer * c.num_layers < free_b / 4;
+        const bool shapes = pkgemm_shape_ok(NQ, H) && pkgemm_shape_ok(H, QDp) && pkgemm_shape_ok(2 * I, H) && pkgemm_shape_ok(H, I) && I % 64 == 0;
+        if (r == PGK_OK && c.weight_format == 0 && shapes && fits && !(ep && atoi(ep) == 0)) {
+            e->packed.resize(c.num_layers);
+            hipStream_t st = resolve_stream(nullptr);
+            for (int l = 0; l < c.num_layers && r == PGK_OK; ++l) {
+                auto& P = e->packed[l];
+                const auto& L = e->layers[l];
+                A((void**)&P.qkv, (size_t)NQ * H * 2, &e->packed_bytes);
+                A((void**)&P.o, (size_t)H * QDp * 2, &e->packed_bytes);
+                A((void**)&P.gate_up, (size_t)2 * I * H * 2, &e->packed_bytes);
+                A((void**)&P.down, (size_t)H * I * 2, &e->packed_bytes);
+                if (r == PGK_OK) r = pack_weights_bf16(L.w_qkv, P.qkv, NQ, H, st);
+                if (r == PGK_OK) r = pack_weights_bf16(L.w_o, P.o, H, QDp, st);
+                if (r == PGK_OK) r = pack_weights_bf16(L.w_gate_up, P.gate_up, 2 * I, H, st);
+                if (r == PGK_OK) r = pack_weights_bf16(L.w_down, P.down, H, I, st);
+            }
+            if (r == PGK_OK && hipStreamSynchronize(st) != hipSuccess) r = set_error(PGK_ERR_HIP, "pgk_engine_create: packing the prefill weights failed");
+            e->packed_ok = r == PGK_OK;
+        }
+    }
     if (r != PGK_OK) { pgk_engine_destroy(e); return r; }
     // RoPE tables in fp32, same formula as the reference (src/pygpukit/llm/layers/rope.py:13-24):
     // freqs = 1/theta^(2i/D) in fp32, angle = float(t) * freq in fp32, cos/sin of that.
@@ -1882,7 +1916,7 @@ pgk_status pgk_engine_bytes(pgk_engine eh, size_t* kv_bytes, size_t* workspace_b
     PGK_REQUIRE(eh, "pgk_engine_bytes: null engine");
     Engine* e = (Engine*)eh;
     if (kv_bytes) *kv_bytes = e->kv_bytes;
-    if (workspace_bytes) *workspace_bytes = e->ws_bytes + e->pf_bytes;
+    if (workspace_bytes) *workspace_bytes = e->ws_bytes + e->pf_bytes + e->packed_bytes;
     return PGK_OK;
 }
 
@@ -1900,9 +1934,14 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     // + split-K slabs of the N = hidden projections on the weight-streaming path (n <= 128)
     const bool ws = n <= 128;
     const int s_o = ws ? wsgemm_pick_splits(H, QD, true) : 1, s_d = ws ? wsgemm_pick_splits(H, I, true) : 1;
-    const int s_qkv = ws ? wsgemm_pick_splits(NQKV, H, true) : 1, s_gu = ws ? wsgemm_pick_splits(2 * I, H, true) : 1;
+    const int s_qkv_ws = ws ? wsgemm_pick_splits(NQKV, H, true) : 1, s_qkv = s_qkv_ws, s_gu = ws ? wsgemm_pick_splits(2 * I, H, true) : 1;
     const int maxk = I > QD ? (I > H ? I : H) : (QD > H ? QD : H);
+    // packed-weight path (ops_pkgemm.hip): bf16 layers, n <= 128; its own split counts for the N = hidden projections
+    const bool pk = ws && e->packed_ok;
+    const int pk_so = pk ? pkgemm_pick_splits(n, H, QD) : 1, pk_sd = pk ? pkgemm_pick_splits(n, H, I) : 1;
+    const bool pk_heads = pk && D == 128;       // QKV epilogue: per-head norm + RoPE + cache write inside the projection
     size_t slab_elems = (size_t)(s_o > s_d ? s_o : s_d) * n * H;
+    if (pk && (size_t)(pk_so > pk_sd ? pk_so : pk_sd) * n * H > slab_elems) slab_elems = (size_t)(pk_so > pk_sd ? pk_so : pk_sd) * n * H;
     if (s_qkv > 1 && (size_t)s_qkv * n * NQKV > slab_elems) slab_elems = (size_t)s_qkv * n * NQKV;
     if (s_gu > 1 && (size_t)s_gu * n * 2 * I > slab_elems) slab_elems = (size_t)s_gu * n * 2 * I;
     const size_t need = (size_t)n * H * 4 + ((size_t)n * H + (size_t)n * NQKV + (size_t)n * QD + (size_t)n * 2 * I + (size_t)n * I) * 2 +
@@ -1978,8 +2017,20 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
         bf16* kc = e->kcache + (size_t)l * e->kv_layer_elems() + (size_t)seq * c.num_kv_heads * c.max_seq_len * D;
         bf16* vc = e->vcache + (size_t)l * e->kv_layer_elems() + (size_t)seq * c.num_kv_heads * c.max_seq_len * D;
         if (pgk_status r = norm((const bf16*)L.attn_norm, fuse_q)) return r;
-        if (pgk_status r = proj_store(fuse_q ? nullptr : x, L.w_qkv, L.s_qkv, qkv, NQKV, H, s_qkv)) return r;
-        {
+        if (pk_heads) {
+            PkArgs hd{};
+            hd.q_gamma = c.use_qk_norm ? (const bf16*)L.q_norm : nullptr;
+            hd.k_gamma = c.use_qk_norm ? (const bf16*)L.k_norm : nullptr;
+            hd.eps = c.norm_eps; hd.rope_cos = e->rope_cos; hd.rope_sin = e->rope_sin; hd.kcache = kc; hd.vcache = vc;
+            hd.hq = c.num_heads; hd.hkv = c.num_kv_heads; hd.max_seq = c.max_seq_len; hd.start_pos = start_pos;
+            if (pgk_status r = pkgemm_nt(x, H, e->packed[l].qkv, qkv, NQKV, PK_EPI_QKV, 1, n, NQKV, H, &hd, st)) return r;
+        } else if (pk) {
+            if (pgk_status r = pkgemm_nt(x, H, e->packed[l].qkv, qkv, NQKV, PK_EPI_BF16, 1, n, NQKV, H, nullptr, st)) return r;
+        } else {
+            if (pgk_status r = proj_store(fuse_q ? nullptr : x, L.w_qkv, L.s_qkv, qkv, NQKV, H, s_qkv)) return r;
+        }
+        if (!pk_heads) {
+            const int s_qkv = pk ? 1 : s_qkv_ws;
             const int nslots = c.num_heads + 2 * c.num_kv_heads;
             const bf16* qg = c.use_qk_norm ? (const bf16*)L.q_norm : nullptr;
             const bf16* kg = c.use_qk_norm ? (const bf16*)L.k_norm : nullptr;
@@ -1996,8 +2047,21 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
         if (pgk_status r = pgk_sdpa_causal(qkv, kc, vc, attn, c.num_heads, c.num_kv_heads, n, kv_len, D, 0.f, D, NQKV,
                                            (int64_t)c.max_seq_len * D, D, D, QD, PGK_BF16, st))
             return r;
-        if (pgk_status r = proj_accum(attn, L.w_o, L.s_o, H, QD, s_o)) return r;
+        // N = hidden projections of the packed path: fp32 split-K slabs summed by the next norm (or h32 += with one split)
+        auto pk_accum = [&](const bf16* x_in, const bf16* wp, int K_, int splits) -> pgk_status {
+            if (splits == 1) return pkgemm_nt(x_in, K_, wp, h32, H, PK_EPI_ACCUM, 1, n, H, K_, nullptr, st);
+            pending = splits;
+            return pkgemm_nt(x_in, K_, wp, slabs, H, PK_EPI_SLAB, splits, n, H, K_, nullptr, st);
+        };
+        if (pk) { if (pgk_status r = pk_accum(attn, e->packed[l].o, QD, pk_so)) return r; }
+        else if (pgk_status r = proj_accum(attn, L.w_o, L.s_o, H, QD, s_o)) return r;
         if (pgk_status r = norm((const bf16*)L.mlp_norm, fuse_q)) return r;
+        if (pk) {
+            // SwiGLU inside the gate_up projection: the gate tile and its up tile live in the same wave
+            if (pgk_status r = pkgemm_nt(x, H, e->packed[l].gate_up, act, I, PK_EPI_SWIGLU, 1, n, 2 * I, H, nullptr, st)) return r;
+            if (pgk_status r = pk_accum(act, e->packed[l].down, I, pk_sd)) return r;
+            continue;
+        }
         if (pgk_status r = proj_store(fuse_q ? nullptr : x, L.w_gate_up, L.s_gate_up, gu, 2 * I, H, s_gu)) return r;
         swiglu_rows_kernel<<<ceil_div((long long)n * I / 8, 256) > 2048 ? 2048 : ceil_div((long long)n * I / 8, 256), 256, 0, st>>>(
             gu, act, n, I, slabs, s_gu > 1 ? s_gu : 0, fuse_q ? q8 : nullptr, fuse_q ? q8s : nullptr);

@@ -1,0 +1,363 @@
+// Packed-weight skinny GEMM for gfx950:  C[M,N] = A[M,K] . W[N,K]^T,  M <= 128 (prefill of a short prompt).
+//
+// Why a second weight layout.  The MFMA B fragment of a ROW-MAJOR weight matrix puts lane l on row l & 15: the 64 lanes
+// of one 16-byte load touch 64 separate 16-byte pieces, and a CU's texture addresser takes those about one lane per
+// clock - 70 cycles per wave-instruction against 20-25 for 1 KiB of consecutive bytes (tools/micro/ta_probe.hip:
+// 8.9 vs 25-31 TB/s chip-wide from L2).  A workgroup that wants its whole weight slice in flight at once pays that per
+// instruction, serially, on its one CU.  So the engine keeps a second copy of the layer weights in FRAGMENT-MAJOR
+// order: block (n-tile, k-step) = 16 rows x 32 k = 1 KiB, lane l's 16 bytes at offset 16 l, blocks of one n-tile
+// consecutive along k.  A wave streaming its n-tile reads one contiguous run (K / 32 KiB), every instruction fully
+// coalesced, no LDS round trip for the read-once operand.  288 GB of HBM is what pays for the copy (bf16 layers only).
+//
+// Shape of a workgroup (4 waves):
+//   * m-block of 32 rows (MT = 2 m-tiles): the grid is (n-blocks x m-blocks x K-splits), with the m-blocks of one
+//     n-block 8 ids apart so they land on the same XCD and share the weight bytes in its L2;
+//   * the whole activation block [32][K_wg] goes global -> LDS by LDS-DMA up front (XOR-swizzled on the source side),
+//     the first 16 k-steps of every wave's weight run are requested right behind it: ONE memory round trip, then a
+//     register ring refilled 16 k-steps ahead of use;
+//   * a wave owns one or two n-tiles (two for the fused epilogues) and reads each A fragment once for both.
+// Epilogues: bf16 store, fp32 split-K slabs, fp32 +=, SwiGLU (gate tile and its up tile in the same wave), and the
+// QKV head epilogue - per-head RMSNorm + RoPE + KV-cache write, a workgroup owning one head of 128 with tiles d and
+// d + 64 in the same wave so the rotate-half pair sits in one lane.
+// Reference: the same projections go through cuBLASLt / CUTLASS 128x128 tiles with separate rmsnorm / rope / silu /
+// mul launches (src/pygpukit/llm/layers/attention.py, mlp.py; native/ops/matmul/matmul.cu:142-235).
+
+#include "gemv_core.cuh"
+#include "pgk_internal.h"
+#include "pkgemm.cuh"
+
+namespace pgk {
+
+typedef __bf16 bf16x8_p __attribute__((ext_vector_type(8)));
+typedef float f32x4_p __attribute__((ext_vector_type(4)));
+
+constexpr int PK_THREADS = 256;
+constexpr int PK_MT = 2;           // m-tiles per workgroup
+constexpr int PK_MB = PK_MT * 16;  // rows per m-block
+constexpr int PK_RING = 16;        // k-steps of weights in flight per n-tile
+
+__device__ __forceinline__ void pk_dma16(const void* src, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ uint32_t pk_lds_addr(const char* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+// 16-byte chunk c of a row lives at chunk position pk_swz(c, row): involution inside aligned groups of 16 chunks
+__device__ __forceinline__ int pk_swz(int c, int row) { return (c & ~15) | ((c ^ row) & 15); }
+
+__global__ void pack_weights_kernel(const bf16* w, bf16* wp, int N, int K) {
+    const size_t chunks = (size_t)N * K / 8, stride = (size_t)gridDim.x * blockDim.x;
+    const int ksn = K / 32;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < chunks; t += stride) {
+        const int l = (int)(t & 63);
+        const size_t blk = t >> 6;
+        const int ks = (int)(blk % ksn), nt = (int)(blk / ksn);
+        const uint4 v = *reinterpret_cast<const uint4*>(w + (size_t)(nt * 16 + (l & 15)) * K + ks * 32 + 8 * (l >> 4));
+        *reinterpret_cast<uint4*>(wp + t * 8) = v;
+    }
+}
+
+pgk_status pack_weights_bf16(const void* w, void* wp, int N, int K, hipStream_t st) {
+    PGK_REQUIRE(N % 16 == 0 && K % 32 == 0, "pack_weights: N=%d must be a multiple of 16 and K=%d of 32", N, K);
+    const size_t chunks = (size_t)N * K / 8;
+    const int grid = (int)(chunks / 256 > 4096 ? 4096 : (chunks + 255) / 256);
+    pack_weights_kernel<<<grid, 256, 0, st>>>((const bf16*)w, (bf16*)wp, N, K);
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
+}
+
+template <int NTW, int EPI>
+__global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char a_lds[];   // [PK_MB][ksteps * 32] bf16, chunk-swizzled rows
+    __shared__ float ssred[4][PK_MB];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, q = lane >> 4;
+    // workgroup id -> (n-block, m-block, split): the m-blocks (and splits) of an n-block sit 8 ids apart = same XCD
+    int cb, mb, sp;
+    {
+        const int id = blockIdx.x;
+        if ((g.nblk & 7) == 0) {
+            const int xcd = id & 7;
+            int rest = id >> 3;
+            mb = rest % g.mblk; rest /= g.mblk;
+            sp = rest % g.splits; rest /= g.splits;
+            cb = rest * 8 + xcd;
+        } else {
+            mb = id % g.mblk;
+            sp = (id / g.mblk) % g.splits;
+            cb = id / (g.mblk * g.splits);
+        }
+    }
+    const int m0 = mb * PK_MB;
+    const int ks0 = sp * g.ksteps, KS = g.ksteps, ksn = g.K / 32;
+    const int rb = KS * 64;                                   // bytes per LDS row
+    const int tile_a = cb * g.tiles_per_cb + wid;
+    const bf16* wrun[NTW];
+    wrun[0] = g.wp + ((size_t)tile_a * ksn + ks0) * 512 + lane * 8;
+    if constexpr (NTW == 2) wrun[1] = g.wp + ((size_t)(tile_a + g.tile_b_off) * ksn + ks0) * 512 + lane * 8;
+
+    // head epilogue: the row's RoPE entries and the gammas are requested before anything else (first in = first out)
+    float cs[PK_MT][4], sn[PK_MT][4], gam[2];
+    bool is_q = false, is_k = false;
+    if constexpr (EPI == PK_EPI_QKV) {
+        is_q = cb < g.hq;
+        is_k = !is_q && cb < g.hq + g.hkv;
+        const int d = 16 * wid + l15;                          // < 64; the wave's second tile holds d + 64
+#pragma unroll
+        for (int mt = 0; mt < PK_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pos = min(g.start_pos + min(m0 + mt * 16 + 4 * q + r, g.M - 1), g.max_seq - 1);
+                cs[mt][r] = g.rope_cos[(size_t)pos * 64 + d];
+                sn[mt][r] = g.rope_sin[(size_t)pos * 64 + d];
+            }
+        const bf16* gm = is_q ? g.q_gamma : g.k_gamma;
+        gam[0] = gam[1] = 1.f;
+        if (gm != nullptr && (is_q || is_k)) { gam[0] = to_f(gm[d]); gam[1] = to_f(gm[d + 64]); }
+    }
+
+    // activation block by LDS-DMA: instruction j fills LDS bytes [1024 j, +1024); lane i's chunk position -> source chunk
+    {
+        const uint32_t lds0 = pk_lds_addr(a_lds);
+        const int ndma = PK_MB * rb / 1024;
+        for (int j = wid; j < ndma; j += 4) {
+            const int P = j * 1024 + lane * 16;
+            const int row = P / rb, cp = (P % rb) >> 4;
+            const int c = pk_swz(cp, row);
+            pk_dma16(g.a + (size_t)min(m0 + row, g.M - 1) * g.lda + (size_t)ks0 * 32 + c * 8, lds0 + j * 1024);
+        }
+    }
+    // weight ring: exactly NTW * PK_RING loads behind the DMAs (clamped k-step: the explicit wait below counts them)
+    uint4 wr[NTW][PK_RING];
+#pragma unroll
+    for (int s = 0; s < PK_RING; ++s)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) wr[t][s] = *reinterpret_cast<const uint4*>(wrun[t] + (size_t)min(s, KS - 1) * 512);   // default cache policy: the other m-blocks re-read these bytes from L2
+    if constexpr (NTW == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // in-order return: every DMA has landed
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __syncthreads();
+
+    f32x4_p acc[NTW][PK_MT];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int mt = 0; mt < PK_MT; ++mt) acc[t][mt] = f32x4_p{0.f, 0.f, 0.f, 0.f};
+
+    uint4 af[2][PK_MT];
+    auto read_a = [&](int ks, uint4 (&dst)[PK_MT]) {
+#pragma unroll
+        for (int mt = 0; mt < PK_MT; ++mt) {
+            const int row = mt * 16 + l15;
+            dst[mt] = *reinterpret_cast<const uint4*>(a_lds + row * rb + (pk_swz(4 * ks + q, row) << 4));
+        }
+    };
+    auto step = [&](int s, const uint4 (&a_cur)[PK_MT]) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const bf16x8_p b = __builtin_bit_cast(bf16x8_p, wr[t][s]);
+#pragma unroll
+            for (int mt = 0; mt < PK_MT; ++mt)
+                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_p, a_cur[mt]), b, acc[t][mt], 0, 0, 0);
+        }
+    };
+    read_a(0, af[0]);
+    const int nfull = KS / PK_RING, rem = KS % PK_RING;
+    for (int blk = 0; blk < nfull; ++blk) {
+#pragma unroll
+        for (int s = 0; s < PK_RING; ++s) {
+            const int ks = blk * PK_RING + s;
+            read_a(min(ks + 1, KS - 1), af[(s + 1) & 1]);
+            step(s, af[s & 1]);
+            if (ks + PK_RING < KS) {                               // wave-uniform
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) wr[t][s] = *reinterpret_cast<const uint4*>(wrun[t] + (size_t)(ks + PK_RING) * 512);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < PK_RING; ++s) {
+        if (s < rem) {
+            const int ks = nfull * PK_RING + s;
+            read_a(min(ks + 1, KS - 1), af[(s + 1) & 1]);
+            step(s, af[s & 1]);
+        }
+    }
+
+    // C/D map: column (weight row) = l15 of the tile, row m = mt * 16 + 4 q + r
+    if constexpr (EPI == PK_EPI_BF16 || EPI == PK_EPI_SLAB || EPI == PK_EPI_ACCUM) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int n = (tile_a + t * g.tile_b_off) * 16 + l15;
+            if constexpr (EPI == PK_EPI_ACCUM) {
+                float* c = reinterpret_cast<float*>(g.c);
+                float old[PK_MT][4];
+#pragma unroll
+                for (int mt = 0; mt < PK_MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) old[mt][r] = c[(size_t)min(m0 + mt * 16 + 4 * q + r, g.M - 1) * g.ldc + n];
+#pragma unroll
+                for (int mt = 0; mt < PK_MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + mt * 16 + 4 * q + r;
+                        if (m < g.M) c[(size_t)m * g.ldc + n] = old[mt][r] + acc[t][mt][r];
+                    }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < PK_MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + mt * 16 + 4 * q + r;
+                        if (m < g.M) {
+                            if constexpr (EPI == PK_EPI_BF16) reinterpret_cast<bf16*>(g.c)[(size_t)m * g.ldc + n] = from_f<bf16>(acc[t][mt][r]);
+                            else (reinterpret_cast<float*>(g.c) + (size_t)sp * g.M * g.ldc)[(size_t)m * g.ldc + n] = acc[t][mt][r];
+                        }
+                    }
+            }
+        }
+    } else if constexpr (EPI == PK_EPI_SWIGLU) {
+        // act = silu(gate) * up on the bf16-rounded projections (what a bf16 gate_up store followed by the activation
+        // kernel computes), one act column per lane
+        const int n = tile_a * 16 + l15;
+        bf16* c = reinterpret_cast<bf16*>(g.c);
+#pragma unroll
+        for (int mt = 0; mt < PK_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + mt * 16 + 4 * q + r;
+                const float gf = to_f(from_f<bf16>(acc[0][mt][r])), uf = to_f(from_f<bf16>(acc[1][mt][r]));
+                if (m < g.M) c[(size_t)m * g.ldc + n] = from_f<bf16>(gf / (1.0f + __expf(-gf)) * uf);
+            }
+    } else {
+        // one head of 128: lane holds dims d = 16 wid + l15 (tile 0) and d + 64 (tile 1) of rows m
+        const int d = 16 * wid + l15;
+        float x0[PK_MT][4], x1[PK_MT][4];
+#pragma unroll
+        for (int mt = 0; mt < PK_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                x0[mt][r] = to_f(from_f<bf16>(acc[0][mt][r]));
+                x1[mt][r] = to_f(from_f<bf16>(acc[1][mt][r]));
+            }
+        if (is_q || is_k) {
+            const bool has_norm = (is_q ? g.q_gamma : g.k_gamma) != nullptr;
+            if (has_norm) {
+#pragma unroll
+                for (int mt = 0; mt < PK_MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float ss = fmaf(x0[mt][r], x0[mt][r], x1[mt][r] * x1[mt][r]);
+                        ss = group16_sum(ss);
+                        if (l15 == 0) ssred[wid][mt * 16 + 4 * q + r] = ss;
+                    }
+                __syncthreads();
+#pragma unroll
+                for (int mt = 0; mt < PK_MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int mi = mt * 16 + 4 * q + r;
+                        const float ss = (ssred[0][mi] + ssred[1][mi]) + (ssred[2][mi] + ssred[3][mi]);
+                        const float inv = 1.0f / sqrtf(ss / 128.f + g.eps);
+                        x0[mt][r] = x0[mt][r] * inv * gam[0];
+                        x1[mt][r] = x1[mt][r] * inv * gam[1];
+                    }
+            }
+#pragma unroll
+            for (int mt = 0; mt < PK_MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a0 = x0[mt][r], a1 = x1[mt][r];
+                    x0[mt][r] = a0 * cs[mt][r] - a1 * sn[mt][r];
+                    x1[mt][r] = a1 * cs[mt][r] + a0 * sn[mt][r];
+                }
+        }
+#pragma unroll
+        for (int mt = 0; mt < PK_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + mt * 16 + 4 * q + r;
+                if (m >= g.M) continue;
+                if (is_q) {
+                    bf16* dst = reinterpret_cast<bf16*>(g.c) + (size_t)m * g.ldc + (size_t)cb * 128;
+                    dst[d] = from_f<bf16>(x0[mt][r]);
+                    dst[d + 64] = from_f<bf16>(x1[mt][r]);
+                } else {
+                    const int pos = g.start_pos + m;
+                    if (pos < g.max_seq) {
+                        const int kvh = is_k ? cb - g.hq : cb - g.hq - g.hkv;
+                        bf16* dst = (is_k ? g.kcache : g.vcache) + ((size_t)kvh * g.max_seq + pos) * 128;
+                        dst[d] = from_f<bf16>(x0[mt][r]);
+                        dst[d + 64] = from_f<bf16>(x1[mt][r]);
+                    }
+                }
+            }
+    }
+}
+
+// K splits for the N = hidden projections: enough workgroups to cover the chip, whole rings where possible
+int pkgemm_pick_splits(int M, int N, int K) {
+    const int nblk = N / 64, mblk = ceil_div(M, PK_MB);
+    int best = 1;
+    for (int s = 1; s <= 16; ++s) {
+        if (K % (s * 128) != 0) continue;
+        if (K / s > 2048) { best = s; continue; }       // LDS: 32 rows x 2048 k
+        best = s;
+        if (nblk * mblk * s >= 256) break;
+    }
+    return best;
+}
+
+bool pkgemm_shape_ok(int N, int K) { return N % 64 == 0 && K % 128 == 0; }
+
+// Packed-weight projection.  epi: PK_EPI_*; `splits` > 1 only with PK_EPI_SLAB.  SwiGLU: N = 2 * I weight rows, c = act [M][I].
+pgk_status pkgemm_nt(const bf16* a, int lda, const void* wp, void* c, int ldc, int epi, int splits, int M, int N, int K, const PkArgs* head,
+                     hipStream_t st) {
+    PGK_REQUIRE(M >= 1 && M <= 128, "pkgemm: M=%d outside [1,128]", M);
+    PGK_REQUIRE(pkgemm_shape_ok(N, K) && lda % 8 == 0, "pkgemm: N=%d K=%d lda=%d not supported", N, K, lda);
+    PGK_REQUIRE(splits >= 1 && K % (splits * 128) == 0 && (epi == PK_EPI_SLAB || splits == 1), "pkgemm: %d K-splits not usable here", splits);
+    PkArgs g = head ? *head : PkArgs{};
+    g.a = a; g.lda = lda; g.wp = (const bf16*)wp; g.M = M; g.N = N; g.K = K; g.c = c; g.ldc = ldc;
+    g.ksteps = K / splits / 32;
+    g.splits = splits;
+    g.mblk = ceil_div(M, PK_MB);
+    g.tiles_per_cb = 4;
+    g.tile_b_off = 0;
+    if (epi == PK_EPI_SWIGLU) {
+        PGK_REQUIRE(N % 128 == 0, "pkgemm: SwiGLU needs 2 I = %d weight rows with I a multiple of 64", N);
+        g.nblk = N / 2 / 64;
+        g.tile_b_off = N / 2 / 16;
+    } else if (epi == PK_EPI_QKV) {
+        PGK_REQUIRE(head && N == (g.hq + 2 * g.hkv) * 128, "pkgemm: head epilogue needs head_dim 128 (N=%d)", N);
+        g.nblk = N / 128;
+        g.tiles_per_cb = 8;
+        g.tile_b_off = 4;
+    } else {
+        g.nblk = N / 64;
+    }
+    const size_t lds = (size_t)PK_MB * g.ksteps * 64;
+    PGK_REQUIRE(lds <= 128 * 1024, "pkgemm: K per workgroup %d too long for the LDS activation block", g.ksteps * 32);
+    const int grid = g.nblk * g.mblk * splits;
+#define PGK_PK_LAUNCH(NTWV, EPIV)                                                                                  \
+    {                                                                                                              \
+        static size_t attr = 0;                                                                                    \
+        if (lds > 48 * 1024 && lds > attr) {                                                                       \
+            PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pkgemm_kernel<NTWV, EPIV>),            \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));     \
+            attr = 128 * 1024;                                                                                     \
+        }                                                                                                          \
+        pkgemm_kernel<NTWV, EPIV><<<grid, PK_THREADS, lds, st>>>(g);                                               \
+    }
+    switch (epi) {
+        case PK_EPI_BF16: PGK_PK_LAUNCH(1, PK_EPI_BF16) break;
+        case PK_EPI_SLAB: PGK_PK_LAUNCH(1, PK_EPI_SLAB) break;
+        case PK_EPI_ACCUM: PGK_PK_LAUNCH(1, PK_EPI_ACCUM) break;
+        case PK_EPI_SWIGLU: PGK_PK_LAUNCH(2, PK_EPI_SWIGLU) break;
+        case PK_EPI_QKV: PGK_PK_LAUNCH(2, PK_EPI_QKV) break;
+        default: return set_error(PGK_ERR_INVALID, "pkgemm: unknown epilogue %d", epi);
+    }
+#undef PGK_PK_LAUNCH
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
+}
+
+}  // namespace pgk

@@ -1,0 +1,36 @@
+// Packed-weight skinny GEMM (ops_pkgemm.hip): arguments and entry points shared with the engine.
+#pragma once
+
+#include "pgk_device.cuh"
+#include "pgk_internal.h"
+
+namespace pgk {
+
+enum { PK_EPI_BF16 = 0, PK_EPI_SLAB = 1, PK_EPI_ACCUM = 2, PK_EPI_SWIGLU = 3, PK_EPI_QKV = 4 };
+
+struct PkArgs {
+    const bf16* a;
+    int lda;
+    const bf16* wp;        // packed [N/16][K/32][64][8]
+    int M, N, K;
+    int ksteps;            // k-steps (32 k) per K split; multiple of 4
+    int nblk, mblk, splits;
+    int tiles_per_cb;      // n-tiles between consecutive n-blocks (4; 8 for the head epilogue)
+    int tile_b_off;        // NTW == 2: the wave's second n-tile is this many tiles after its first
+    void* c;
+    int ldc;
+    // head epilogue
+    const bf16 *q_gamma, *k_gamma;
+    float eps;
+    const float *rope_cos, *rope_sin;
+    bf16 *kcache, *vcache;
+    int hq, hkv, max_seq, start_pos;
+};
+
+pgk_status pack_weights_bf16(const void* w, void* wp, int N, int K, hipStream_t st);
+int pkgemm_pick_splits(int M, int N, int K);
+bool pkgemm_shape_ok(int N, int K);
+pgk_status pkgemm_nt(const bf16* a, int lda, const void* wp, void* c, int ldc, int epi, int splits, int M, int N, int K, const PkArgs* head,
+                     hipStream_t st);
+
+}  // namespace pgk

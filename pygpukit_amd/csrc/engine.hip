@@ -1005,6 +1005,7 @@ __global__ void embed_rows_kernel(const bf16* embed, const int32_t* tokens, floa
 // With q8 != nullptr (fp8-activation prefill, H % 128 == 0) the row leaves as e4m3 codes + one fp32 scale per 128
 // columns instead of bf16: the values quantised are the bf16-rounded ones, so this is bit-identical to
 // rmsnorm -> quantize_rows_kernel without the second pass over the activations.
+template <int NS>   // slab loads issued per trip (>= nslabs): 4 on the packed path, 16 covers every split count of wsgemm
 __global__ __launch_bounds__(256) void rmsnorm_f32_bf16_kernel(float* h, const bf16* gamma, bf16* out, int rows, int H,
                                                                float eps, const float* slabs, int nslabs,
                                                                uint8_t* q8 = nullptr, float* q8s = nullptr) {
@@ -1013,19 +1014,25 @@ __global__ __launch_bounds__(256) void rmsnorm_f32_bf16_kernel(float* h, const b
     float* hr = h + (size_t)row * H;
     constexpr int MAXT = 4;                     // H <= 4096 handled in registers
     float4 v[MAXT];
+    uint2 gm[MAXT];                             // gamma requested with the row: not a second round trip after the reduction
     float ss = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int i = (threadIdx.x + t * 256) * 4;
+        gm[t] = *reinterpret_cast<const uint2*>(gamma + min(i, H - 4));
+    }
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         const int i = (threadIdx.x + t * 256) * 4;
         if (i < H) {                            // block-uniform per t when H % 1024 == 0; otherwise per-lane tail
             float4 acc = *reinterpret_cast<const float4*>(hr + i);
             if (nslabs > 0) {
-                float4 p[16];
+                float4 p[NS];
 #pragma unroll
-                for (int s = 0; s < 16; ++s)
+                for (int s = 0; s < NS; ++s)
                     p[s] = *reinterpret_cast<const float4*>(slabs + ((size_t)min(s, nslabs - 1) * rows + row) * H + i);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
+                for (int s = 0; s < NS; ++s) {
                     const float w = s < nslabs ? 1.f : 0.f;
                     acc.x = fmaf(w, p[s].x, acc.x); acc.y = fmaf(w, p[s].y, acc.y);
                     acc.z = fmaf(w, p[s].z, acc.z); acc.w = fmaf(w, p[s].w, acc.w);
@@ -1042,7 +1049,7 @@ __global__ __launch_bounds__(256) void rmsnorm_f32_bf16_kernel(float* h, const b
     for (int t = 0; t < MAXT; ++t) {
         const int i = (threadIdx.x + t * 256) * 4;
         if (i < H) {
-            const uint2 g = *reinterpret_cast<const uint2*>(gamma + i);
+            const uint2 g = gm[t];
             const float g0 = __uint_as_float(g.x << 16), g1 = __uint_as_float(g.x & 0xFFFF0000u);
             const float g2 = __uint_as_float(g.y << 16), g3 = __uint_as_float(g.y & 0xFFFF0000u);
             uint2 o;
@@ -2003,8 +2010,12 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
         return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, out_, nullptr, 0, 1, n, N_, K_, st);
     };
     auto norm = [&](const bf16* gamma, bool to_fp8 = false) -> pgk_status {
-        rmsnorm_f32_bf16_kernel<<<n, 256, 0, st>>>(h32, gamma, x, n, H, c.norm_eps, slabs, pending, to_fp8 ? q8 : nullptr,
-                                                   to_fp8 ? q8s : nullptr);
+        if (pending <= 4)
+            rmsnorm_f32_bf16_kernel<4><<<n, 256, 0, st>>>(h32, gamma, x, n, H, c.norm_eps, slabs, pending, to_fp8 ? q8 : nullptr,
+                                                          to_fp8 ? q8s : nullptr);
+        else
+            rmsnorm_f32_bf16_kernel<16><<<n, 256, 0, st>>>(h32, gamma, x, n, H, c.norm_eps, slabs, pending, to_fp8 ? q8 : nullptr,
+                                                           to_fp8 ? q8s : nullptr);
         pending = 0;
         PGK_LAUNCH_CHECK();
         return PGK_OK;

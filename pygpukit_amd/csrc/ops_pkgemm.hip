@@ -116,15 +116,19 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
         if (gm != nullptr && (is_q || is_k)) { gam[0] = to_f(gm[d]); gam[1] = to_f(gm[d + 64]); }
     }
 
-    // activation block by LDS-DMA: instruction j fills LDS bytes [1024 j, +1024); lane i's chunk position -> source chunk
+    // activation block by LDS-DMA: instruction j fills LDS bytes [1024 j, +1024) = four 256-byte swizzle groups; lane i sits
+    // in group 4 j + (i >> 4) at chunk position i & 15.  row = group / groups-per-row through a 16-bit reciprocal (exact for
+    // the <= 2048 groups of a block, no integer division in the issue path).
     {
         const uint32_t lds0 = pk_lds_addr(a_lds);
-        const int ndma = PK_MB * rb / 1024;
+        const int ndma = PK_MB * rb / 1024, gpr = KS >> 2;
+        const uint32_t magic = (65536u + gpr - 1) / gpr;
+        const bf16* abase = g.a + (size_t)ks0 * 32;
         for (int j = wid; j < ndma; j += 4) {
-            const int P = j * 1024 + lane * 16;
-            const int row = P / rb, cp = (P % rb) >> 4;
-            const int c = pk_swz(cp, row);
-            pk_dma16(g.a + (size_t)min(m0 + row, g.M - 1) * g.lda + (size_t)ks0 * 32 + c * 8, lds0 + j * 1024);
+            const int grp = 4 * j + q;
+            const int row = (int)(((uint32_t)grp * magic) >> 16), gi = grp - row * gpr;
+            const int c = gi * 16 + ((l15 ^ row) & 15);
+            pk_dma16(abase + (size_t)min(m0 + row, g.M - 1) * g.lda + c * 8, lds0 + j * 1024);
         }
     }
     // weight ring: exactly NTW * PK_RING loads behind the DMAs (clamped k-step: the explicit wait below counts them)
@@ -143,13 +147,17 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
 #pragma unroll
         for (int mt = 0; mt < PK_MT; ++mt) acc[t][mt] = f32x4_p{0.f, 0.f, 0.f, 0.f};
 
+    // A fragment of k-step ks: row mt * 16 + l15, chunk 4 ks + q at its swizzled position.  With ks = 4 a + j the byte
+    // offset is rowbase + 256 a + 16 ((4 j + q) ^ (row & 15)): the four XOR terms are per-lane constants
     uint4 af[2][PK_MT];
-    auto read_a = [&](int ks, uint4 (&dst)[PK_MT]) {
+    int aoff[PK_MT][4];
 #pragma unroll
-        for (int mt = 0; mt < PK_MT; ++mt) {
-            const int row = mt * 16 + l15;
-            dst[mt] = *reinterpret_cast<const uint4*>(a_lds + row * rb + (pk_swz(4 * ks + q, row) << 4));
-        }
+    for (int mt = 0; mt < PK_MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aoff[mt][j] = (mt * 16 + l15) * rb + ((((4 * j + q) ^ l15) & 15) << 4);
+    auto read_a = [&](int ks, int j, uint4 (&dst)[PK_MT]) {   // j == ks & 3 (compile-time at every call site)
+#pragma unroll
+        for (int mt = 0; mt < PK_MT; ++mt) dst[mt] = *reinterpret_cast<const uint4*>(a_lds + aoff[mt][j] + ((ks >> 2) << 8));
     };
     auto step = [&](int s, const uint4 (&a_cur)[PK_MT]) {
 #pragma unroll
@@ -160,13 +168,13 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
                 acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_p, a_cur[mt]), b, acc[t][mt], 0, 0, 0);
         }
     };
-    read_a(0, af[0]);
+    read_a(0, 0, af[0]);
     const int nfull = KS / PK_RING, rem = KS % PK_RING;
     for (int blk = 0; blk < nfull; ++blk) {
 #pragma unroll
         for (int s = 0; s < PK_RING; ++s) {
             const int ks = blk * PK_RING + s;
-            read_a(min(ks + 1, KS - 1), af[(s + 1) & 1]);
+            read_a(min(ks + 1, KS - 4 + ((s + 1) & 3)), (s + 1) & 3, af[(s + 1) & 1]);
             step(s, af[s & 1]);
             if (ks + PK_RING < KS) {                               // wave-uniform
 #pragma unroll
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
     for (int s = 0; s < PK_RING; ++s) {
         if (s < rem) {
             const int ks = nfull * PK_RING + s;
-            read_a(min(ks + 1, KS - 1), af[(s + 1) & 1]);
+            read_a(min(ks + 1, KS - 4 + ((s + 1) & 3)), (s + 1) & 3, af[(s + 1) & 1]);
             step(s, af[s & 1]);
         }
     }

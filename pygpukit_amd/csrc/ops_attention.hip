@@ -178,6 +178,142 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const T* q, const T*
     }
 }
 
+// ---- whole context in one tile: kv_len <= 128, head_dim 128, bf16 -------------------------------------------------
+// A prompt of up to 128 tokens needs no online softmax and no K/V loop, and the 64-row flash kernel above spends its ~10 us
+// on three barriers per 64-position tile and on transposing V with 2-byte LDS writes.  Here:
+//   * 32 query rows per workgroup (2 waves; 4 x heads workgroups), K and V rows [0, needed) staged once, row-major;
+//   * TRANSPOSED scores S^T = K.Q^T: the C layout then gives every lane ONE query row (column = lane & 15) and four
+//     consecutive positions per tile, so max / sum are lane-local plus two 16-lane-stride shuffles, and the probabilities
+//     of tiles 2s, 2s+1 packed to bf16 ARE the operand of the second product with no LDS round trip - the k-slot of
+//     element j of lane quarter q is position 32 s + 16 (j >> 2) + 4 q + (j & 3), and V is read with the same slots;
+//   * V comes out of its row-major image through ds_read_b64_tr_b16 (gfx950's transposing LDS read), two per fragment;
+//   * O^T = V^T.P^T: a lane ends with 4 consecutive dims of its query row per tile = one 8-byte store, 1/l per lane.
+// Layout (b) of the CDNA guide (T10) for the V image: 256-byte rows, chunk ch at ch ^ (((row & 3) << 2) | ((row >> 2) & 3)).
+typedef short sa_v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int sa_voff(int row, int ch) { return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_short_kernel(const bf16* q, const bf16* k, const bf16* v, bf16* out, int hq, int hkv,
+                                                             int q_len, int kv_len, float scale, AttnStrides sd) {
+    constexpr int D = 128, NT = 8;
+    __shared__ __attribute__((aligned(16))) char k_lds[128 * 256];
+    __shared__ __attribute__((aligned(16))) char v_lds[128 * 256];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, q4 = lane >> 4;
+    const int head = blockIdx.y, kvh = head / (hq / hkv);
+    const int qb0 = blockIdx.x * (16 * NW), q0 = qb0 + wid * 16;
+    const int causal_off = kv_len - q_len;
+    const bf16* qh = q + (size_t)head * sd.qh;
+    const bf16* kh = k + (size_t)kvh * sd.kh;
+    const bf16* vh = v + (size_t)kvh * sd.kh;
+    // query fragments first (the B operand of S^T): row l15 of this wave's tile, dims 32 ks + 8 q4 .. + 8
+    uint4 qf[4];
+    const int qrow = q0 + l15;
+    {
+        const bf16* qp = qh + (size_t)min(qrow, q_len - 1) * sd.qs + 8 * q4;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(qp + 32 * ks);
+    }
+    // positions this workgroup can see, in whole 32-position steps (rows past kv_len come from a clamped address and are masked).
+    // Staging is LDS-DMA: one instruction moves 4 rows x 256 bytes, lane i -> row 4 j + (i >> 4), chunk POSITION i & 15, and
+    // the swizzle of each image is applied on the source side (both are XORs of the chunk index: involutions).  A loop of
+    // load -> ds_write pairs here costs one memory round trip per iteration (the first version: 10.6 us, no faster than
+    // the flash kernel); the DMAs are all in flight at once and hold no registers.
+    const int kv_need = min(kv_len, causal_off + min(qb0 + 16 * NW, q_len));
+    const int nstep = (kv_need + 31) >> 5;
+    {
+        const uint32_t k0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)k_lds;
+        const uint32_t v0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)v_lds;
+        auto dma = [](const void* src, uint32_t lds_addr) {
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+        };
+        const int ninst = nstep * 8;                       // 4 rows each
+        for (int j = wid; j < ninst; j += NW) {
+            const int r = 4 * j + q4;
+            dma(kh + (size_t)min(r, kv_len - 1) * sd.ks + ((l15 ^ (r & 15)) << 3), k0 + j * 1024);
+        }
+        for (int j = wid; j < ninst; j += NW) {
+            const int r = 4 * j + q4;
+            dma(vh + (size_t)min(r, kv_len - 1) * sd.ks + ((l15 ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 3), v0 + j * 1024);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs (and its query fragments); the barrier makes the images everyone's
+    __syncthreads();
+    // this wave's own horizon (wave-uniform): tiles of 16 positions it needs
+    const int my_need = min(kv_len, causal_off + min(q0 + 16, q_len));
+    const int my_steps = (my_need + 31) >> 5;
+    f32x4_t s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if ((t >> 1) < my_steps) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 ka = *reinterpret_cast<const uint4*>(k_lds + tD_off<D>(t * 16 + l15, ks * 4 + q4));
+                s[t] = mfma16a<bf16>(ka, qf[ks], s[t]);          // rows = positions 16 t + 4 q4 + r, column = query row l15
+            }
+        }
+    }
+    const int last_ok = min(kv_len - 1, causal_off + qrow);       // last position query row `qrow` may attend
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = (t >> 1) < my_steps && 16 * t + 4 * q4 + r <= last_ok;
+            s[t][r] = ok ? s[t][r] * scale : -INFINITY;
+            mx = fmaxf(mx, s[t][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float ls = 0.f;
+    uint4 pf[NT / 2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float p[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = (mx == -INFINITY) ? 0.f : __expf(s[t][r] - mx);
+        const uint32_t lo = pack_bf16x2(p[0], p[1]), hi = pack_bf16x2(p[2], p[3]);
+        // the sum runs over the ROUNDED probabilities: numerator and denominator see the same weights
+        ls += (__uint_as_float(lo << 16) + __uint_as_float(lo & 0xFFFF0000u)) + (__uint_as_float(hi << 16) + __uint_as_float(hi & 0xFFFF0000u));
+        if (t & 1) { pf[t >> 1].z = lo; pf[t >> 1].w = hi; } else { pf[t >> 1].x = lo; pf[t >> 1].y = hi; }
+    }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    // O^T[d][q] += V^T[d][kv] P^T[kv][q] over steps of 32 positions; lane (l15, q4) of the A operand supplies the address of
+    // row (l15 >> 2) of its 16-lane group's 4 x 16 block, columns 4 (l15 & 3) .. + 4
+    f32x4_t o[D / 16];
+#pragma unroll
+    for (int i = 0; i < D / 16; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int tq = l15 >> 2, tp = l15 & 3;
+#pragma unroll
+    for (int st2 = 0; st2 < NT / 2; ++st2) {
+        if (st2 < my_steps) {
+            const int r0 = 32 * st2 + 4 * q4 + tq;
+#pragma unroll
+            for (int i = 0; i < D / 16; ++i) {
+                const sa_v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) sa_v4s*)(v_lds + sa_voff(r0, 2 * i + (tp >> 1)) + 8 * (tp & 1)));
+                const sa_v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) sa_v4s*)(v_lds + sa_voff(r0 + 16, 2 * i + (tp >> 1)) + 8 * (tp & 1)));
+                const uint2 u0 = __builtin_bit_cast(uint2, a0), u1 = __builtin_bit_cast(uint2, a1);
+                o[i] = mfma16a<bf16>(make_uint4(u0.x, u0.y, u1.x, u1.y), pf[st2], o[i]);   // rows = dims 16 i + 4 q4 + r, column = query row l15
+            }
+        }
+    }
+    if (qrow < q_len) {
+        const float inv = ls > 0.f ? 1.f / ls : 0.f;
+        bf16* op = out + (size_t)head * sd.oh + (size_t)qrow * sd.os + 4 * q4;
+#pragma unroll
+        for (int i = 0; i < D / 16; ++i) {
+            uint2 w;
+            w.x = pack_bf16x2(o[i][0] * inv, o[i][1] * inv);
+            w.y = pack_bf16x2(o[i][2] * inv, o[i][3] * inv);
+            *reinterpret_cast<uint2*>(op + 16 * i) = w;
+        }
+    }
+}
+
 // fp32 / odd head_dim fallback: one workgroup per (head, query row), scores kept in LDS.
 template <class T>
 __global__ __launch_bounds__(256) void sdpa_naive_kernel(const T* q, const T* k, const T* v, T* out, int hq, int hkv,
@@ -308,6 +444,16 @@ static pgk_status sdpa_dispatch(const void* q, const void* k, const void* v, voi
         if (gen2_ok && (gen == 1 || (gen < 0 && q_len > 128)))
             return flash_prefill(q, k, v, out, hq, hkv, q_len, kv_len, d, scale, sd.qh, sd.qs, sd.kh, sd.ks, sd.oh, sd.os,
                                  std::is_same<T, f16>::value ? 1 : 0, st);
+        if constexpr (std::is_same<T, bf16>::value) {
+            // the whole context in one tile (attn_short_kernel); PGK_ATTN_SHORT=0 keeps the flash kernel
+            static const bool short_off = [] { const char* e = getenv("PGK_ATTN_SHORT"); return e && atoi(e) == 0; }();
+            if (gen2_ok && !short_off && d == 128 && kv_len <= 128 && gen < 0) {
+                attn_short_kernel<2><<<dim3(ceil_div(q_len, 32), hq), 128, 0, st>>>((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, hq, hkv,
+                                                                                  q_len, kv_len, scale, sd);
+                PGK_CHECK_HIP(hipGetLastError());
+                return PGK_OK;
+            }
+        }
         if (mfma_ok) {
             if (d == 128) return launch_prefill<T, 128>((const T*)q, (const T*)k, (const T*)v, (T*)out, hq, hkv, q_len, kv_len, scale, sd, st);
             return launch_prefill<T, 64>((const T*)q, (const T*)k, (const T*)v, (T*)out, hq, hkv, q_len, kv_len, scale, sd, st);

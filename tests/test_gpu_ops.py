@@ -656,6 +656,8 @@ def test_sdpa_golden_fp32(tag):
 @pytest.mark.parametrize("dt", ["bfloat16", "float16"])
 @pytest.mark.parametrize("cfg", [(4, 4, 9, 9, 128), (4, 2, 3, 11, 64), (16, 8, 128, 128, 128), (8, 2, 70, 200, 128),
                                  (2, 2, 130, 130, 64), (4, 1, 1, 37, 128),
+                                 # kv_len <= 128 at head_dim 128 (bf16): the one-tile kernel, ragged rows and a kv offset
+                                 (8, 2, 70, 100, 128), (2, 1, 33, 128, 128), (4, 4, 17, 17, 128),
                                  # q_len > 128: the transposed-score kernel (ops_flash.hip), incl. ragged tiles and kv offset
                                  (4, 2, 129, 129, 128), (8, 2, 300, 300, 128), (2, 1, 257, 400, 128), (4, 4, 513, 513, 64),
                                  (2, 2, 200, 1000, 64)])

@@ -1254,6 +1254,8 @@ struct Engine {
     std::vector<PackedLayer> packed;
     bool packed_ok = false;
     size_t packed_bytes = 0;
+    float* dec_slabs = nullptr;     // 17..64 sequences on the packed kernels: split-K slabs of o_proj / down_proj [splits][M][H] (PGK_PACKED_DECODE=0: engine_batched kernels)
+    bool packed_decode = false;
     // prefill workspace (grown on demand, outside capture)
     void* pf = nullptr;
     size_t pf_bytes = 0;
@@ -1678,6 +1680,79 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
     return PGK_OK;
 }
 
+// 17..64 sequences, bf16 layers: the step on the fragment-major weight copy (ops_pkgemm.hip) - the prefill's kernels with
+// one row per SEQUENCE.  Seven launches per layer as on the tiled path, but the projections stream coalesced 1 KiB
+// fragments with the activation block in LDS by DMA, SwiGLU sits in the gate_up epilogue, and the N = hidden projections
+// are split along K over 256 workgroups with the next RMSNorm summing their slabs (rmsnorm_f32_bf16_kernel, as in
+// pgk_engine_prefill).  Attention (per-sequence positions, new-token norm / RoPE / cache write) is the batch kernel.
+static pgk_status decode_chunk_packed(Engine* e, int b0, int M, bool last, hipStream_t st, int* launches) {
+    const auto& c = e->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size, D = c.head_dim, QD = c.num_heads * D, NQKV = e->qkv_dim();
+    float* h = e->h + (size_t)b0 * H;
+    bf16* x16 = e->x16 + (size_t)b0 * H;
+    const bool direct = e->attn_direct_ok && M >= 3;
+    const int s_o = pkgemm_pick_splits(M, H, QD), s_d = pkgemm_pick_splits(M, H, I);
+    int pending = 0;
+    auto norm = [&](const bf16* gamma) -> pgk_status {
+        mark(KC_NORM_QKV);
+        // (plain launches, like the projections of this path: the per-launch probe and the in-kernel timeline cover the
+        // kernels that take a timeline pointer - attention, lm_head, finalize)
+        if (pending <= 4) rmsnorm_f32_bf16_kernel<4><<<M, 256, 0, st>>>(h, gamma, x16, M, H, c.norm_eps, e->dec_slabs, pending);
+        else rmsnorm_f32_bf16_kernel<16><<<M, 256, 0, st>>>(h, gamma, x16, M, H, c.norm_eps, e->dec_slabs, pending);
+        pending = 0;
+        PGK_LAUNCH_CHECK();
+        return PGK_OK;
+    };
+    for (int l = 0; l < c.num_layers; ++l) {
+        const auto& L = e->layers[l];
+        const auto& P = e->packed[l];
+        if (pgk_status r = norm((const bf16*)L.attn_norm)) return r;
+        if (pgk_status r = pkgemm_nt(x16, H, P.qkv, e->qkv + (size_t)b0 * NQKV, NQKV, PK_EPI_SLAB, 1, M, NQKV, H, nullptr, st)) return r;
+        mark(KC_ATTN);
+        if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, false, st, true)) return r; }
+        else { if (pgk_status r = launch_attn<64>(e, l, b0, M, false, st, true)) return r; }
+        mark(KC_OPROJ);
+        bf16* attn16 = e->attnv16 + (size_t)b0 * QD;
+        if (!direct) {   // long contexts: the merge kernel leaves fp32 rows
+            if (pgk_status r = norm_rows_bf16(e->attnv + (size_t)b0 * QD, nullptr, attn16, M, QD, 0.f, st)) return r;
+            *launches += 1;
+        }
+        if (pgk_status r = pkgemm_nt(attn16, QD, P.o, e->dec_slabs, H, PK_EPI_SLAB, s_o, M, H, QD, nullptr, st)) return r;
+        pending = s_o;
+        if (pgk_status r = norm((const bf16*)L.mlp_norm)) return r;
+        mark(KC_GATEUP);
+        bf16* act16 = e->act16 + (size_t)b0 * I;
+        if (pgk_status r = pkgemm_nt(x16, H, P.gate_up, act16, I, PK_EPI_SWIGLU, 1, M, 2 * I, H, nullptr, st)) return r;
+        mark(KC_DOWN);
+        if (pgk_status r = pkgemm_nt(act16, I, P.down, e->dec_slabs, H, PK_EPI_SLAB, s_d, M, H, I, nullptr, st)) return r;
+        pending = s_d;
+        *launches += ((direct || e->merge_cnt) ? 7 : 8) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;
+    }
+    const int nblk = ceil_div(c.vocab_size, 16) < 2048 ? ceil_div(c.vocab_size, 16) : 2048;
+    if (pgk_status r = norm(e->final_norm)) return r;     // also folds the last down_proj's slabs into the residual stream
+    mark(KC_LMHEAD);
+    FusedArgs a{};
+    a.w = e->lm_head; a.N = c.vocab_size; a.K = H;
+    a.h = h; a.gamma = e->final_norm; a.eps = c.norm_eps;
+    a.out = e->logits + (size_t)b0 * c.vocab_size; a.ld_out = c.vocab_size;
+    a.amax_val = e->amax_val + (size_t)b0 * e->lm_cap; a.amax_idx = e->amax_idx + (size_t)b0 * e->lm_cap;
+    a.xin16 = x16;
+    if (pgk_status r = batched_proj(false, PRO_PLAIN, EPI_LOGITS, a, M, st, nblk)) return r;
+    mark(KC_ARGMAX);
+    const int32_t* sampled = nullptr;
+    if (e->sample_temperature > 0.f) {
+        if (pgk_status r = engine_sample(e, b0, M, st)) return r;
+        sampled = e->sampled + b0;
+        *launches += 1;
+    }
+    PGK_CHECK_HIP(launch_k(finalize_kernel, dim3(M), dim3(256), 0, st, a.amax_val, a.amax_idx, nblk, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
+                                       e->cfg.max_batch, e->log_cap, e->embed, h, H, last ? 1 : 0, b0 == 0 ? e->clk_log : nullptr,
+                                       e->rope_cos, e->rope_sin, e->cur_cos + (size_t)b0 * (D / 2), e->cur_sin + (size_t)b0 * (D / 2),
+                                       D / 2, c.max_seq_len, M, sampled, (unsigned*)nullptr));
+    *launches += 3;
+    return PGK_OK;
+}
+
 template <class WT>
 static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* launches, hipStream_t st2) {
     int b0 = 0;
@@ -1689,7 +1764,12 @@ static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* la
         // kernels exist for M = 1, 2, 4, 8 only, so 3 / 5 / 6 / 7 sequences would take two or three weight passes there
         // (measured: 7 sequences 2.46 ms against 1.05).  GEMV stays for exactly 1, 2 and 4 (0.70 / 0.93 / 0.82 ms).
         const bool mfma_ok = e->batched_mfma && (rem >= e->batched_min || (e->batched_min == 5 && rem == 3));
-        if (mfma_ok) { const int m = rem > e->batched_max ? e->batched_max : rem; r = decode_chunk_batched<WT>(e, b0, m, rem == m, st, launches); b0 += m; }
+        if (mfma_ok) {
+            const int m = rem > e->batched_max ? e->batched_max : rem;
+            if (m > 16 && e->packed_decode && !std::is_same<WT, fp8e4m3>::value) r = decode_chunk_packed(e, b0, m, rem == m, st, launches);
+            else r = decode_chunk_batched<WT>(e, b0, m, rem == m, st, launches);
+            b0 += m;
+        }
         else if (rem >= 8) { r = decode_chunk<WT, bf16, 8>(e, b0, rem == 8, st, launches); b0 += 8; }
         else if (rem >= 4) { r = decode_chunk<WT, bf16, 4>(e, b0, rem == 4, st, launches); b0 += 4; }
         else if (rem >= 2) { r = decode_chunk<WT, float, 2>(e, b0, rem == 2, st, launches); b0 += 2; }
@@ -1851,7 +1931,7 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         const size_t per_layer = ((size_t)NQ * H + (size_t)H * QDp + (size_t)2 * I * H + (size_t)H * I) * 2;
         size_t free_b = 0, total_b = 0;
         const bool fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && per_layer * c.num_layers < free_b / 4;
-        const bool shapes = pkgemm_shape_ok(NQ, H) && pkgemm_shape_ok(H, QDp) && pkgemm_shape_ok(2 * I, H) && pkgemm_shape_ok(H, I) && I % 64 == 0;
+        const bool shapes = pkgemm_shape_ok(NQ, H, false) && pkgemm_shape_ok(H, QDp, true) && pkgemm_shape_ok(2 * I, H, false) && pkgemm_shape_ok(H, I, true) && I % 64 == 0;
         if (r == PGK_OK && c.weight_format == 0 && shapes && fits && !(ep && atoi(ep) == 0)) {
             e->packed.resize(c.num_layers);
             hipStream_t st = resolve_stream(nullptr);
@@ -1869,6 +1949,11 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
             }
             if (r == PGK_OK && hipStreamSynchronize(st) != hipSuccess) r = set_error(PGK_ERR_HIP, "pgk_engine_create: packing the prefill weights failed");
             e->packed_ok = r == PGK_OK;
+            const char* pd = getenv("PGK_PACKED_DECODE");
+            if (e->packed_ok && c.max_batch > 16 && !(pd && atoi(pd) == 0)) {
+                A((void**)&e->dec_slabs, (size_t)16 * 64 * H * 4, &e->ws_bytes);
+                e->packed_decode = r == PGK_OK;
+            }
         }
     }
     if (r != PGK_OK) { pgk_engine_destroy(e); return r; }

@@ -66,10 +66,19 @@ pgk_status pack_weights_bf16(const void* w, void* wp, int N, int K, hipStream_t 
     return PGK_OK;
 }
 
+#ifdef PGK_PHASE_STAMPS
+// diagnostic build only (tools/pk_stamps.py): 100 MHz stamps of workgroup phases, last launch of each epilogue kind
+__device__ unsigned long long g_pk_stamps[5][512][8];
+#define PK_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 512) g_pk_stamps[EPI][blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PK_STAMP(i) do { } while (0)
+#endif
+
 template <int NTW, int EPI>
 __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
     extern __shared__ __attribute__((aligned(16))) char a_lds[];   // [PK_MB][ksteps * 32] bf16, chunk-swizzled rows
     __shared__ float ssred[4][PK_MB];
+    PK_STAMP(0);
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, q = lane >> 4;
     // workgroup id -> (n-block, m-block, split): the m-blocks (and splits) of an n-block sit 8 ids apart = same XCD
@@ -96,24 +105,27 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
     wrun[0] = g.wp + ((size_t)tile_a * ksn + ks0) * 512 + lane * 8;
     if constexpr (NTW == 2) wrun[1] = g.wp + ((size_t)(tile_a + g.tile_b_off) * ksn + ks0) * 512 + lane * 8;
 
-    // head epilogue: the row's RoPE entries and the gammas are requested before anything else (first in = first out)
-    float cs[PK_MT][4], sn[PK_MT][4], gam[2];
+    // head epilogue: the m-block's RoPE rows (32 positions x 64 floats, cos and sin) go to LDS by 16 DMA instructions and
+    // the gammas are requested first of all (first in = first out).  (Per-lane loads of the 16 entries a lane needs were
+    // 64 more wave-instructions through the CU's texture addresser, which is what bounds this kernel's first 2.8 us.)
+    __shared__ __attribute__((aligned(16))) float rope_lds[EPI == PK_EPI_QKV ? 2 * PK_MB * 64 : 4];
+    float gam[2];
     bool is_q = false, is_k = false;
     if constexpr (EPI == PK_EPI_QKV) {
         is_q = cb < g.hq;
         is_k = !is_q && cb < g.hq + g.hkv;
         const int d = 16 * wid + l15;                          // < 64; the wave's second tile holds d + 64
-#pragma unroll
-        for (int mt = 0; mt < PK_MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int pos = min(g.start_pos + min(m0 + mt * 16 + 4 * q + r, g.M - 1), g.max_seq - 1);
-                cs[mt][r] = g.rope_cos[(size_t)pos * 64 + d];
-                sn[mt][r] = g.rope_sin[(size_t)pos * 64 + d];
-            }
         const bf16* gm = is_q ? g.q_gamma : g.k_gamma;
         gam[0] = gam[1] = 1.f;
         if (gm != nullptr && (is_q || is_k)) { gam[0] = to_f(gm[d]); gam[1] = to_f(gm[d + 64]); }
+        if (is_q || is_k) {
+            const uint32_t r0 = pk_lds_addr(reinterpret_cast<const char*>(rope_lds));
+            for (int j = wid; j < 16; j += 4) {                // instruction j: table j >> 3, rows 4 (j & 7) + q, 16 bytes per lane
+                const int row = 4 * (j & 7) + q;
+                const int pos = min(g.start_pos + min(m0 + row, g.M - 1), g.max_seq - 1);
+                pk_dma16(((j >> 3) ? g.rope_sin : g.rope_cos) + (size_t)pos * 64 + 4 * l15, r0 + j * 1024);
+            }
+        }
     }
 
     // activation block by LDS-DMA: instruction j fills LDS bytes [1024 j, +1024) = four 256-byte swizzle groups; lane i sits
@@ -137,9 +149,11 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
     for (int s = 0; s < PK_RING; ++s)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) wr[t][s] = *reinterpret_cast<const uint4*>(wrun[t] + (size_t)min(s, KS - 1) * 512);   // default cache policy: the other m-blocks re-read these bytes from L2
+    PK_STAMP(1);
     if constexpr (NTW == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // in-order return: every DMA has landed
     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __syncthreads();
+    PK_STAMP(2);
 
     f32x4_p acc[NTW][PK_MT];
 #pragma unroll
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
 
     // A fragment of k-step ks: row mt * 16 + l15, chunk 4 ks + q at its swizzled position.  With ks = 4 a + j the byte
     // offset is rowbase + 256 a + 16 ((4 j + q) ^ (row & 15)): the four XOR terms are per-lane constants
-    uint4 af[2][PK_MT];
+    uint4 af[4][PK_MT];
     int aoff[PK_MT][4];
 #pragma unroll
     for (int mt = 0; mt < PK_MT; ++mt)
@@ -168,29 +182,39 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
                 acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_p, a_cur[mt]), b, acc[t][mt], 0, 0, 0);
         }
     };
+    // fragments are read TWO k-steps ahead of the MFMAs that use them: with one wave per SIMD nothing else hides the LDS
+    // latency, and one step (4 MFMAs = 64 cycles) does not cover it (in-kernel stamps: 16 k-steps took 1.15 us against
+    // 0.43 us of MFMA time with a one-step lead)
+    auto ahead = [&](int ks, int s2) {   // fragment of k-step ks + 2 into slot (s2 + 2) & 3; s2 = ks mod 16 at every call site
+        const int j = (s2 + 2) & 3;
+        read_a(min(ks + 2, KS - 4 + j), j, af[(s2 + 2) & 3]);
+    };
     read_a(0, 0, af[0]);
+    read_a(1, 1, af[1]);
     const int nfull = KS / PK_RING, rem = KS % PK_RING;
     for (int blk = 0; blk < nfull; ++blk) {
 #pragma unroll
         for (int s = 0; s < PK_RING; ++s) {
             const int ks = blk * PK_RING + s;
-            read_a(min(ks + 1, KS - 4 + ((s + 1) & 3)), (s + 1) & 3, af[(s + 1) & 1]);
-            step(s, af[s & 1]);
+            ahead(ks, s);
+            step(s, af[s & 3]);
             if (ks + PK_RING < KS) {                               // wave-uniform
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) wr[t][s] = *reinterpret_cast<const uint4*>(wrun[t] + (size_t)(ks + PK_RING) * 512);
             }
         }
+        if (blk == 0) PK_STAMP(3);
     }
 #pragma unroll
     for (int s = 0; s < PK_RING; ++s) {
         if (s < rem) {
             const int ks = nfull * PK_RING + s;
-            read_a(min(ks + 1, KS - 4 + ((s + 1) & 3)), (s + 1) & 3, af[(s + 1) & 1]);
-            step(s, af[s & 1]);
+            ahead(ks, s);
+            step(s, af[s & 3]);
         }
     }
 
+    PK_STAMP(4);
     // C/D map: column (weight row) = l15 of the tile, row m = mt * 16 + 4 q + r
     if constexpr (EPI == PK_EPI_BF16 || EPI == PK_EPI_SLAB || EPI == PK_EPI_ACCUM) {
 #pragma unroll
@@ -274,9 +298,11 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
             for (int mt = 0; mt < PK_MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    const int mi = mt * 16 + 4 * q + r;
+                    const float cs = rope_lds[mi * 64 + d], sn = rope_lds[PK_MB * 64 + mi * 64 + d];
                     const float a0 = x0[mt][r], a1 = x1[mt][r];
-                    x0[mt][r] = a0 * cs[mt][r] - a1 * sn[mt][r];
-                    x1[mt][r] = a1 * cs[mt][r] + a0 * sn[mt][r];
+                    x0[mt][r] = a0 * cs - a1 * sn;
+                    x1[mt][r] = a1 * cs + a0 * sn;
                 }
         }
 #pragma unroll
@@ -300,28 +326,38 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
                 }
             }
     }
+    PK_STAMP(5);
 }
 
-// K splits for the N = hidden projections: enough workgroups to cover the chip, whole rings where possible
+#ifdef PGK_PHASE_STAMPS
+extern "C" int pgk_debug_pk_stamps(unsigned long long* out) {   // [5][512][8]
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pk_stamps), sizeof(g_pk_stamps));
+}
+#endif
+
+// K splits for the N = hidden projections: enough workgroups to cover the chip, and a K range per workgroup whose
+// activation block (32 rows) fits the LDS budget.  0: no split count works for this K.
 int pkgemm_pick_splits(int M, int N, int K) {
     const int nblk = N / 64, mblk = ceil_div(M, PK_MB);
-    int best = 1;
+    int best = 0;
     for (int s = 1; s <= 16; ++s) {
-        if (K % (s * 128) != 0) continue;
-        if (K / s > 2048) { best = s; continue; }       // LDS: 32 rows x 2048 k
+        if (K % (s * 128) != 0 || K / s > 2048) continue;
         best = s;
         if (nblk * mblk * s >= 256) break;
     }
     return best;
 }
 
-bool pkgemm_shape_ok(int N, int K) { return N % 64 == 0 && K % 128 == 0; }
+// splittable: the projection may be cut along K (slab epilogue); otherwise one workgroup walks the whole K
+bool pkgemm_shape_ok(int N, int K, bool splittable) {
+    return N % 64 == 0 && K % 128 == 0 && (splittable ? pkgemm_pick_splits(128, N, K) > 0 : K <= 2048);
+}
 
 // Packed-weight projection.  epi: PK_EPI_*; `splits` > 1 only with PK_EPI_SLAB.  SwiGLU: N = 2 * I weight rows, c = act [M][I].
 pgk_status pkgemm_nt(const bf16* a, int lda, const void* wp, void* c, int ldc, int epi, int splits, int M, int N, int K, const PkArgs* head,
                      hipStream_t st) {
     PGK_REQUIRE(M >= 1 && M <= 128, "pkgemm: M=%d outside [1,128]", M);
-    PGK_REQUIRE(pkgemm_shape_ok(N, K) && lda % 8 == 0, "pkgemm: N=%d K=%d lda=%d not supported", N, K, lda);
+    PGK_REQUIRE(N % 64 == 0 && K % 128 == 0 && lda % 8 == 0, "pkgemm: N=%d K=%d lda=%d not supported", N, K, lda);
     PGK_REQUIRE(splits >= 1 && K % (splits * 128) == 0 && (epi == PK_EPI_SLAB || splits == 1), "pkgemm: %d K-splits not usable here", splits);
     PkArgs g = head ? *head : PkArgs{};
     g.a = a; g.lda = lda; g.wp = (const bf16*)wp; g.M = M; g.N = N; g.K = K; g.c = c; g.ldc = ldc;

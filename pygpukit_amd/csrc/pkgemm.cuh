@@ -29,7 +29,7 @@ struct PkArgs {
 
 pgk_status pack_weights_bf16(const void* w, void* wp, int N, int K, hipStream_t st);
 int pkgemm_pick_splits(int M, int N, int K);
-bool pkgemm_shape_ok(int N, int K);
+bool pkgemm_shape_ok(int N, int K, bool splittable);
 pgk_status pkgemm_nt(const bf16* a, int lda, const void* wp, void* c, int ldc, int epi, int splits, int M, int N, int K, const PkArgs* head,
                      hipStream_t st);
 

@@ -1,4 +1,4 @@
-"""Decode-step workload for rocprofv3: tools/decode_prof.py <batch> [steps] [prompt_len] [bf16|fp8]
+"""Decode-step workload for rocprofv3: tools/decode_prof.py <batch> [steps] [prompt_len] [bf16|fp8] [eager]
     cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d <out> -- python3 tools/decode_prof.py 64 20"""
 import os, sys, time
 import numpy as np
@@ -13,7 +13,14 @@ eng = S.build_engine_from_weights(cfg, w, max_seq_len=P + steps + 16, max_batch=
 pr = np.random.default_rng(1).integers(0, cfg["vocab_size"], (B, P))
 first = [int(np.argmax(eng.prefill([int(t) for t in pr[b]], seq=b))) for b in range(B)]
 eng.set_state(first, [P] * B)
-eng.capture(B)
-eng.replay(4); eng.synchronize()
-t0 = time.perf_counter(); eng.replay(steps); eng.synchronize(); dt = time.perf_counter() - t0
+eager = len(sys.argv) > 5 and sys.argv[5] == "eager"   # un-captured steps: rocprofv3 (ROCm 7.2) crashes inside hipGraphLaunch on graphs that hold the packed-weight kernels
+if eager:
+    def run(n):
+        for _ in range(n):
+            eng.decode_step(B)
+else:
+    eng.capture(B)
+    run = eng.replay
+run(4); eng.synchronize()
+t0 = time.perf_counter(); run(steps); eng.synchronize(); dt = time.perf_counter() - t0
 print(f"batch {B} ctx {P} {fmt}: {dt * 1e3 / steps:.3f} ms/step, {B * steps / dt:.0f} tok/s, {eng.launches_per_step()} launches/step")

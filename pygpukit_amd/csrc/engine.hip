@@ -677,8 +677,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
     __builtin_amdgcn_sched_barrier(0);
     const int pos = load_uniform_i32(a.positions + b);   // scalar path (pgk_device.cuh): not queued behind the vector loads in flight
     const int ctx = min(pos + 1, a.max_seq);
+    tls.phase(0);
     NewToken<D, G> t;
     new_token_finish<D, G>(a, lane, raw, t);
+    tls.phase(1);
     const int c1 = min(c0 + chunk, ctx);
     const bool owns_new = (pos < a.max_seq) && (pos >= c0) && (pos < c0 + chunk);
     if (owns_new && wid == 0 && lane < LPR && a.g_off == 0) {
@@ -692,6 +694,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
     if (cend > c0 + U1 * 4 * PPW)
         decode_walk_trips<D, G>(a.kcache + head_off, a.vcache + head_off, c0 + U1 * 4 * PPW, cend, t.qb, lane, wid, st);
     if (owns_new && wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
+    tls.phase(2);
     if constexpr (DIRECT) {
         // this workgroup saw the whole context: normalise here and skip the merge launch
         decode_block_merge_lds<D, G>(st, lds, attn_out, lane, wid);
@@ -925,6 +928,18 @@ __global__ __launch_bounds__(256) void attn_merge_oproj_kernel(AttnArgs a, unsig
         m = hrecs[((size_t)wid * a.nsplit + sc) * RS];
         l = hrecs[((size_t)wid * a.nsplit + sc) * RS + 1];
     }
+    // ... and the records' value words of this thread's output element(s): up to 32 slices per element straight into
+    // registers, BEFORE the W_o stream and before the barrier below.  (They used to be read after the barrier, eight at a
+    // time: three to four dependent L2 round trips on the critical path of every layer at context 2048.)
+    constexpr int EPT = (GD + 255) / 256, RPRE = 32;
+    float rv[EPT][RPRE];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = min((int)threadIdx.x + 256 * i, GD - 1), g = e / D, d = e % D;
+        const float* recs = hrecs + (size_t)g * a.nsplit * RS + 2 + d;
+#pragma unroll
+        for (int u = 0; u < RPRE; ++u) rv[i][u] = recs[(size_t)min(u, a.nsplit - 1) * RS];
+    }
     __builtin_amdgcn_sched_barrier(0);
     uint4 pre[PRE];
     float psc[PRE];
@@ -935,6 +950,7 @@ __global__ __launch_bounds__(256) void attn_merge_oproj_kernel(AttnArgs a, unsig
         if constexpr (FP8) psc[p] = to_f(a.w_o_scale[(size_t)(row >> 7) * (ldw >> 7) + (col0 >> 7)]);
     }
     __builtin_amdgcn_sched_barrier(0);
+    tls.phase(0);
     if (wid < G) {
         if (lane >= a.nsplit) { m = -INFINITY; l = 0.f; }
         const float mx = wave_max(m);
@@ -944,22 +960,22 @@ __global__ __launch_bounds__(256) void attn_merge_oproj_kernel(AttnArgs a, unsig
         if (lane == 0) inv_l[wid] = tot > 0.f ? 1.0f / tot : 0.f;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < GD; e += 256) {
-        const int g = e / D, d = e % D;
-        const float* recs = hrecs + (size_t)g * a.nsplit * RS;
-        float o = 0.f;
-        int s = 0;
-        for (; s + 8 <= a.nsplit; s += 8) {
-            float v[8];
+    tls.phase(1);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = recs[(size_t)(s + u) * RS + 2 + d];
+    for (int i = 0; i < EPT; ++i) {
+        const int e = (int)threadIdx.x + 256 * i;
+        if (e < GD) {
+            const int g = e / D, d = e % D;
+            const float* recs = hrecs + (size_t)g * a.nsplit * RS;
+            float o = 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) o = fmaf(w_s[g][s + u], v[u], o);
+            for (int u = 0; u < RPRE; ++u) o = fmaf(u < a.nsplit ? w_s[g][u] : 0.f, rv[i][u], o);   // same order as attn_merge_kernel
+            for (int s2 = RPRE; s2 < a.nsplit; ++s2) o = fmaf(w_s[g][s2], recs[(size_t)s2 * RS + 2 + d], o);
+            attn[e] = o * inv_l[g];
         }
-        for (; s < a.nsplit; ++s) o = fmaf(w_s[g][s], recs[(size_t)s * RS + 2 + d], o);
-        attn[e] = o * inv_l[g];
     }
     __syncthreads();
+    tls.phase(2);
     float xf[NWT];
 #pragma unroll
     for (int i = 0; i < NWT / 4; ++i) {

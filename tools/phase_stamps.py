@@ -7,8 +7,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from pygpukit_amd.llm import synthetic as S
 cfg = dict(S.QWEN3_0_6B, num_layers=8)
 w = S.make_qwen3_weights(cfg, seed=0)
-eng = S.build_engine_from_weights(cfg, w, max_seq_len=512, max_batch=1)
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+fmt = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+eng = S.build_engine_from_weights(cfg, w, max_seq_len=512 if P < 400 else P + 64, max_batch=1, weight_format=fmt)
 pr = [int(t) for t in np.random.default_rng(1).integers(0, cfg["vocab_size"], P)]
 first = int(np.argmax(eng.prefill(pr)))
 eng.set_state([first], [P])

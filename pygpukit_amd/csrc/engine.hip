@@ -1270,6 +1270,7 @@ struct Engine {
     std::vector<PackedLayer> packed;
     bool packed_ok = false;
     size_t packed_bytes = 0;
+    bf16* packed_lm = nullptr;      // fragment-major lm_head for the packed decode step (vocab % 64 == 0)
     float* dec_slabs = nullptr;     // 17..64 sequences on the packed kernels: split-K slabs of o_proj / down_proj [splits][M][H] (PGK_PACKED_DECODE=0: engine_batched kernels)
     bool packed_decode = false;
     // prefill workspace (grown on demand, outside capture)
@@ -1744,7 +1745,7 @@ static pgk_status decode_chunk_packed(Engine* e, int b0, int M, bool last, hipSt
         pending = s_d;
         *launches += ((direct || e->merge_cnt) ? 7 : 8) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;
     }
-    const int nblk = ceil_div(c.vocab_size, 16) < 2048 ? ceil_div(c.vocab_size, 16) : 2048;
+    int nblk = ceil_div(c.vocab_size, 16) < 2048 ? ceil_div(c.vocab_size, 16) : 2048;
     if (pgk_status r = norm(e->final_norm)) return r;     // also folds the last down_proj's slabs into the residual stream
     mark(KC_LMHEAD);
     FusedArgs a{};
@@ -1753,7 +1754,13 @@ static pgk_status decode_chunk_packed(Engine* e, int b0, int M, bool last, hipSt
     a.out = e->logits + (size_t)b0 * c.vocab_size; a.ld_out = c.vocab_size;
     a.amax_val = e->amax_val + (size_t)b0 * e->lm_cap; a.amax_idx = e->amax_idx + (size_t)b0 * e->lm_cap;
     a.xin16 = x16;
-    if (pgk_status r = batched_proj(false, PRO_PLAIN, EPI_LOGITS, a, M, st, nblk)) return r;
+    if (e->packed_lm && c.vocab_size / 64 <= e->lm_cap) {
+        // lm_head on its packed copy: one argmax partial per (row, 64-column block) for finalize_kernel
+        nblk = c.vocab_size / 64;
+        PkArgs la{};
+        la.amax_val = a.amax_val; la.amax_idx = a.amax_idx; la.amax_ld = nblk;
+        if (pgk_status r = pkgemm_nt(x16, H, e->packed_lm, a.out, c.vocab_size, PK_EPI_LOGITS, 1, M, c.vocab_size, H, &la, st)) return r;
+    } else if (pgk_status r = batched_proj(false, PRO_PLAIN, EPI_LOGITS, a, M, st, nblk)) return r;
     mark(KC_ARGMAX);
     const int32_t* sampled = nullptr;
     if (e->sample_temperature > 0.f) {
@@ -1969,6 +1976,12 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
             if (e->packed_ok && c.max_batch > 16 && !(pd && atoi(pd) == 0)) {
                 A((void**)&e->dec_slabs, (size_t)16 * 64 * H * 4, &e->ws_bytes);
                 e->packed_decode = r == PGK_OK;
+                const char* pl = getenv("PGK_PACKED_LMHEAD");
+                if (e->packed_decode && pkgemm_shape_ok(c.vocab_size, H, false) && !(pl && atoi(pl) == 0)) {
+                    A((void**)&e->packed_lm, (size_t)c.vocab_size * H * 2, &e->packed_bytes);
+                    if (r == PGK_OK) r = pack_weights_bf16(e->lm_head, e->packed_lm, c.vocab_size, H, st);
+                    if (r == PGK_OK && hipStreamSynchronize(st) != hipSuccess) r = set_error(PGK_ERR_HIP, "pgk_engine_create: packing the lm_head failed");
+                }
             }
         }
     }

@@ -253,6 +253,21 @@ __global__ __launch_bounds__(256) void batched_reg_kernel(FusedArgs a, int M, in
     float wsc[NT][S];
     auto load_w = [&](int n0) {
         const int nrow = min(n0 + l15, N - 1);
+        if constexpr (!FP8 && RPG == 16) {
+            // fragment-major copy (ops_pkgemm.hip): block (n-tile, k-step) is this very fragment, 1 KiB in lane order - one
+            // coalesced load per k-step instead of 64 separate 16-byte pieces of a row-major matrix (3.5x the texture
+            // addresser's time per instruction, tools/micro/ta_probe.hip).  Used where a workgroup streams many groups (lm_head).
+            if (a.wp != nullptr && n0 + 16 <= N) {
+                const int ksn = K >> 5;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bf16* run = a.wp + (((size_t)((t == 0 ? n0 : N + n0) >> 4) * ksn + (kw0 >> 5)) * 64 + lane) * 8;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) wv[t][s] = load_nt16(run + (size_t)s * 512);
+                }
+                return;
+            }
+        }
         if (wlane) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {

@@ -188,6 +188,7 @@ enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3 };
 struct FusedArgs {
     const void* w;        // [N,K] (SWIGLU: [2*N,K], gate rows then up rows)
     const bf16* wscale;   // fp8 block scales or null
+    const bf16* wp;       // batched_reg_kernel, bf16, 16 rows per workgroup: the same weights in fragment-major order (ops_pkgemm.hip) or null
     int N, K;
     const float* h;       // PRO_NORM / PRO_NORM_SUM: [M][K] residual stream
     const bf16* gamma;

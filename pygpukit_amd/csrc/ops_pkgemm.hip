@@ -68,7 +68,7 @@ pgk_status pack_weights_bf16(const void* w, void* wp, int N, int K, hipStream_t 
 
 #ifdef PGK_PHASE_STAMPS
 // diagnostic build only (tools/pk_stamps.py): 100 MHz stamps of workgroup phases, last launch of each epilogue kind
-__device__ unsigned long long g_pk_stamps[6][512][8];
+__device__ unsigned long long g_pk_stamps[5][512][8];
 #define PK_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 512) g_pk_stamps[EPI][blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define PK_STAMP(i) do { } while (0)
@@ -244,39 +244,6 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
                     }
             }
         }
-    } else if constexpr (EPI == PK_EPI_LOGITS) {
-        // fp32 logits + this n-block's best (value, column) per row: lanes of a row first, then the four waves through LDS
-        __shared__ float bvs[4][PK_MB];
-        __shared__ int bis[4][PK_MB];
-        const int n = tile_a * 16 + l15;
-        float* c = reinterpret_cast<float*>(g.c);
-#pragma unroll
-        for (int mt = 0; mt < PK_MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mi = mt * 16 + 4 * q + r, m = m0 + mi;
-                float v = acc[0][mt][r];
-                int ix = n;
-                if (m < g.M) c[(size_t)m * g.ldc + n] = v;
-#pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) {
-                    const float ov = __shfl_xor(v, off, 64);
-                    const int oi = __shfl_xor(ix, off, 64);
-                    if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
-                }
-                if (l15 == 0) { bvs[wid][mi] = v; bis[wid][mi] = ix; }
-            }
-        __syncthreads();
-        if (threadIdx.x < PK_MB && m0 + (int)threadIdx.x < g.M) {
-            const int mi = threadIdx.x;
-            float v = bvs[0][mi];
-            int ix = bis[0][mi];
-#pragma unroll
-            for (int w = 1; w < 4; ++w)
-                if (bvs[w][mi] > v || (bvs[w][mi] == v && bis[w][mi] < ix)) { v = bvs[w][mi]; ix = bis[w][mi]; }
-            g.amax_val[(size_t)(m0 + mi) * g.amax_ld + cb] = v;
-            g.amax_idx[(size_t)(m0 + mi) * g.amax_ld + cb] = ix;
-        }
     } else if constexpr (EPI == PK_EPI_SWIGLU) {
         // act = silu(gate) * up on the bf16-rounded projections (what a bf16 gate_up store followed by the activation
         // kernel computes), one act column per lane
@@ -360,7 +327,7 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
 }
 
 #ifdef PGK_PHASE_STAMPS
-extern "C" int pgk_debug_pk_stamps(unsigned long long* out) {   // [6][512][8]
+extern "C" int pgk_debug_pk_stamps(unsigned long long* out) {   // [5][512][8]
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pk_stamps), sizeof(g_pk_stamps));
 }
 #endif
@@ -427,10 +394,6 @@ pgk_status pkgemm_nt(const bf16* a, int lda, const void* wp, void* c, int ldc, i
         case PK_EPI_ACCUM: PGK_PK_LAUNCH(1, PK_EPI_ACCUM) break;
         case PK_EPI_SWIGLU: PGK_PK_LAUNCH(2, PK_EPI_SWIGLU) break;
         case PK_EPI_QKV: PGK_PK_LAUNCH(2, PK_EPI_QKV) break;
-        case PK_EPI_LOGITS:
-            PGK_REQUIRE(head && g.amax_val && g.amax_idx && g.amax_ld >= g.nblk, "pkgemm: logits epilogue needs the argmax partial buffers (%d slots per row)", g.nblk);
-            PGK_PK_LAUNCH(1, PK_EPI_LOGITS)
-            break;
         default: return set_error(PGK_ERR_INVALID, "pkgemm: unknown epilogue %d", epi);
     }
 #undef PGK_PK_LAUNCH

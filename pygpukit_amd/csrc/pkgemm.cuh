@@ -6,7 +6,7 @@
 
 namespace pgk {
 
-enum { PK_EPI_BF16 = 0, PK_EPI_SLAB = 1, PK_EPI_ACCUM = 2, PK_EPI_SWIGLU = 3, PK_EPI_QKV = 4, PK_EPI_LOGITS = 5 };
+enum { PK_EPI_BF16 = 0, PK_EPI_SLAB = 1, PK_EPI_ACCUM = 2, PK_EPI_SWIGLU = 3, PK_EPI_QKV = 4 };
 
 struct PkArgs {
     const bf16* a;
@@ -25,10 +25,6 @@ struct PkArgs {
     const float *rope_cos, *rope_sin;
     bf16 *kcache, *vcache;
     int hq, hkv, max_seq, start_pos;
-    // logits epilogue: fp32 rows to c, and per (row, n-block) the best value and its column (lowest index on ties)
-    float* amax_val;
-    int* amax_idx;
-    int amax_ld;
 };
 
 pgk_status pack_weights_bf16(const void* w, void* wp, int N, int K, hipStream_t st);

@@ -1270,7 +1270,7 @@ struct Engine {
     std::vector<PackedLayer> packed;
     bool packed_ok = false;
     size_t packed_bytes = 0;
-    bf16* packed_lm = nullptr;      // fragment-major lm_head for the batched (3..16 sequences) lm_head kernel; PGK_PACKED_LMHEAD=0: none
+    bf16* packed_lm = nullptr;      // fragment-major lm_head for the batched (3..64 sequences) lm_head kernels; PGK_PACKED_LMHEAD=0: none
     float* dec_slabs = nullptr;     // 17..64 sequences on the packed kernels: split-K slabs of o_proj / down_proj [splits][M][H] (PGK_PACKED_DECODE=0: engine_batched kernels)
     bool packed_decode = false;
     // prefill workspace (grown on demand, outside capture)
@@ -1755,6 +1755,7 @@ static pgk_status decode_chunk_packed(Engine* e, int b0, int M, bool last, hipSt
     a.out = e->logits + (size_t)b0 * c.vocab_size; a.ld_out = c.vocab_size;
     a.amax_val = e->amax_val + (size_t)b0 * e->lm_cap; a.amax_idx = e->amax_idx + (size_t)b0 * e->lm_cap;
     a.xin16 = x16;
+    a.wp = e->packed_lm;                                  // the M-tiled lm_head streams the fragment-major copy too
     // (lm_head on a packed copy with an argmax epilogue was built and measured: 1.342 ms per step against 1.331 at 64
     // sequences - its 39 MB of fp32 logits stores, not the weight loads, are what the row-major kernel's 95 us are made of)
     if (pgk_status r = batched_proj(false, PRO_PLAIN, EPI_LOGITS, a, M, st, nblk)) return r;

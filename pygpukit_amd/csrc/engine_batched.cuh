@@ -464,6 +464,18 @@ __global__ __launch_bounds__(256) void batched_mt_kernel(FusedArgs a, int M, int
     float wsc[NT][S];
     auto load_w = [&](int n0) {
         const int nrow = min(n0 + l15, N - 1);
+        if constexpr (!FP8 && RPG == 16) {
+            if (a.wp != nullptr && n0 + 16 <= N) {          // fragment-major copy: see batched_reg_kernel
+                const int ksn = K >> 5;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bf16* run = a.wp + (((size_t)((t == 0 ? n0 : N + n0) >> 4) * ksn + (kw0 >> 5)) * 64 + lane) * 8;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) wv[t][s] = load_nt16(run + (size_t)s * 512);
+                }
+                return;
+            }
+        }
         if (wlane) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {

@@ -1270,6 +1270,8 @@ struct Engine {
     std::vector<PackedLayer> packed;
     bool packed_ok = false;
     size_t packed_bytes = 0;
+    bool packed_resid = false;      // o_proj / down_proj without K split, carrying the next RMSNorm (pkgemm_resid_nt); PGK_PACKED_RESID=0: split-K slabs + norm launches
+    float* pk_ss = nullptr;         // its sum-of-squares table [128][PK_SS_LD]
     bf16* packed_lm = nullptr;      // fragment-major lm_head for the batched (3..64 sequences) lm_head kernels; PGK_PACKED_LMHEAD=0: none
     float* dec_slabs = nullptr;     // 17..64 sequences on the packed kernels: split-K slabs of o_proj / down_proj [splits][M][H] (PGK_PACKED_DECODE=0: engine_batched kernels)
     bool packed_decode = false;
@@ -1721,11 +1723,15 @@ static pgk_status decode_chunk_packed(Engine* e, int b0, int M, bool last, hipSt
         PGK_LAUNCH_CHECK();
         return PGK_OK;
     };
+    const bool carried = e->packed_resid;      // o_proj / down_proj carry the next RMSNorm: 5 launches per layer instead of 7
+    int ss_n = 0;
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& L = e->layers[l];
         const auto& P = e->packed[l];
-        if (pgk_status r = norm((const bf16*)L.attn_norm)) return r;
-        if (pgk_status r = pkgemm_nt(x16, H, P.qkv, e->qkv + (size_t)b0 * NQKV, NQKV, PK_EPI_SLAB, 1, M, NQKV, H, nullptr, st)) return r;
+        PkArgs nrm{};
+        if (carried && l > 0) { nrm.ss_in = e->pk_ss; nrm.ss_n = ss_n; nrm.ss_eps = c.norm_eps; }
+        else if (pgk_status r = norm((const bf16*)L.attn_norm)) return r;
+        if (pgk_status r = pkgemm_nt(x16, H, P.qkv, e->qkv + (size_t)b0 * NQKV, NQKV, PK_EPI_SLAB, 1, M, NQKV, H, &nrm, st)) return r;
         mark(KC_ATTN);
         if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, false, st, true)) return r; }
         else { if (pgk_status r = launch_attn<64>(e, l, b0, M, false, st, true)) return r; }
@@ -1735,11 +1741,23 @@ static pgk_status decode_chunk_packed(Engine* e, int b0, int M, bool last, hipSt
             if (pgk_status r = norm_rows_bf16(e->attnv + (size_t)b0 * QD, nullptr, attn16, M, QD, 0.f, st)) return r;
             *launches += 1;
         }
+        bf16* act16 = e->act16 + (size_t)b0 * I;
+        if (carried) {
+            if (pgk_status r = pkgemm_resid_nt(attn16, QD, P.o, h, M, H, QD, (const bf16*)L.mlp_norm, x16, e->pk_ss, &ss_n, nullptr, 0, 0.f, st)) return r;
+            mark(KC_GATEUP);
+            PkArgs gn{};
+            gn.ss_in = e->pk_ss; gn.ss_n = ss_n; gn.ss_eps = c.norm_eps;
+            if (pgk_status r = pkgemm_nt(x16, H, P.gate_up, act16, I, PK_EPI_SWIGLU, 1, M, 2 * I, H, &gn, st)) return r;
+            mark(KC_DOWN);
+            const bf16* gnext = l + 1 < c.num_layers ? (const bf16*)e->layers[l + 1].attn_norm : nullptr;
+            if (pgk_status r = pkgemm_resid_nt(act16, I, P.down, h, M, H, I, gnext, x16, e->pk_ss, &ss_n, nullptr, 0, 0.f, st)) return r;
+            *launches += ((direct || e->merge_cnt) ? 5 : 6) + (l == 0 ? 1 : 0) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;
+            continue;
+        }
         if (pgk_status r = pkgemm_nt(attn16, QD, P.o, e->dec_slabs, H, PK_EPI_SLAB, s_o, M, H, QD, nullptr, st)) return r;
         pending = s_o;
         if (pgk_status r = norm((const bf16*)L.mlp_norm)) return r;
         mark(KC_GATEUP);
-        bf16* act16 = e->act16 + (size_t)b0 * I;
         if (pgk_status r = pkgemm_nt(x16, H, P.gate_up, act16, I, PK_EPI_SWIGLU, 1, M, 2 * I, H, nullptr, st)) return r;
         mark(KC_DOWN);
         if (pgk_status r = pkgemm_nt(act16, I, P.down, e->dec_slabs, H, PK_EPI_SLAB, s_d, M, H, I, nullptr, st)) return r;
@@ -1970,6 +1988,11 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
             }
             if (r == PGK_OK && hipStreamSynchronize(st) != hipSuccess) r = set_error(PGK_ERR_HIP, "pgk_engine_create: packing the prefill weights failed");
             e->packed_ok = r == PGK_OK;
+            const char* pr = getenv("PGK_PACKED_RESID");
+            if (e->packed_ok && pkgemm_resid_ok(H, QDp) && pkgemm_resid_ok(H, I) && !(pr && atoi(pr) == 0)) {
+                A((void**)&e->pk_ss, (size_t)128 * PK_SS_LD * 4, &e->ws_bytes);
+                e->packed_resid = r == PGK_OK;
+            }
             const char* pl = getenv("PGK_PACKED_LMHEAD");
             if (e->packed_ok && c.max_batch >= 3 && c.vocab_size % 16 == 0 && H % 32 == 0 && !(pl && atoi(pl) == 0)) {
                 A((void**)&e->packed_lm, (size_t)c.vocab_size * H * 2, &e->packed_bytes);
@@ -2135,20 +2158,26 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     embed_rows_kernel<<<n, 256, 0, st>>>(e->embed, e->pf_tokens, h32, H);
     PGK_LAUNCH_CHECK();
     const int kv_len = start_pos + n;
+    int ss_n = 0;    // partial sums per row in pk_ss (carried norms)
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& L = e->layers[l];
         bf16* kc = e->kcache + (size_t)l * e->kv_layer_elems() + (size_t)seq * c.num_kv_heads * c.max_seq_len * D;
         bf16* vc = e->vcache + (size_t)l * e->kv_layer_elems() + (size_t)seq * c.num_kv_heads * c.max_seq_len * D;
-        if (pgk_status r = norm((const bf16*)L.attn_norm, fuse_q)) return r;
+        // packed path with carried norms: layer 0 normalises with a launch; afterwards x holds bf16(h * gamma) and pk_ss the
+        // row statistics, both left by the previous layer's down_proj
+        const bool carried = pk && e->packed_resid;
+        PkArgs nrm{};                                   // how the consumer of x scales its rows (all null: x is normalised)
+        if (carried && l > 0) { nrm.ss_in = e->pk_ss; nrm.ss_n = ss_n; nrm.ss_eps = c.norm_eps; }
+        else if (pgk_status r = norm((const bf16*)L.attn_norm, fuse_q)) return r;
         if (pk_heads) {
-            PkArgs hd{};
+            PkArgs hd = nrm;
             hd.q_gamma = c.use_qk_norm ? (const bf16*)L.q_norm : nullptr;
             hd.k_gamma = c.use_qk_norm ? (const bf16*)L.k_norm : nullptr;
             hd.eps = c.norm_eps; hd.rope_cos = e->rope_cos; hd.rope_sin = e->rope_sin; hd.kcache = kc; hd.vcache = vc;
             hd.hq = c.num_heads; hd.hkv = c.num_kv_heads; hd.max_seq = c.max_seq_len; hd.start_pos = start_pos;
             if (pgk_status r = pkgemm_nt(x, H, e->packed[l].qkv, qkv, NQKV, PK_EPI_QKV, 1, n, NQKV, H, &hd, st)) return r;
         } else if (pk) {
-            if (pgk_status r = pkgemm_nt(x, H, e->packed[l].qkv, qkv, NQKV, PK_EPI_BF16, 1, n, NQKV, H, nullptr, st)) return r;
+            if (pgk_status r = pkgemm_nt(x, H, e->packed[l].qkv, qkv, NQKV, PK_EPI_BF16, 1, n, NQKV, H, &nrm, st)) return r;
         } else {
             if (pgk_status r = proj_store(fuse_q ? nullptr : x, L.w_qkv, L.s_qkv, qkv, NQKV, H, s_qkv)) return r;
         }
@@ -2176,6 +2205,17 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
             pending = splits;
             return pkgemm_nt(x_in, K_, wp, slabs, H, PK_EPI_SLAB, splits, n, H, K_, nullptr, st);
         };
+        if (carried) {
+            // o_proj adds the residual itself and leaves bf16(h * gamma_mlp) + row statistics; gate_up scales by 1 / rms;
+            // down_proj does the same for the next layer's attention norm: 5 launches per layer
+            if (pgk_status r = pkgemm_resid_nt(attn, QD, e->packed[l].o, h32, n, H, QD, (const bf16*)L.mlp_norm, x, e->pk_ss, &ss_n, nullptr, 0, 0.f, st)) return r;
+            PkArgs gn{};
+            gn.ss_in = e->pk_ss; gn.ss_n = ss_n; gn.ss_eps = c.norm_eps;
+            if (pgk_status r = pkgemm_nt(x, H, e->packed[l].gate_up, act, I, PK_EPI_SWIGLU, 1, n, 2 * I, H, &gn, st)) return r;
+            const bf16* gnext = l + 1 < c.num_layers ? (const bf16*)e->layers[l + 1].attn_norm : nullptr;
+            if (pgk_status r = pkgemm_resid_nt(act, I, e->packed[l].down, h32, n, H, I, gnext, x, e->pk_ss, &ss_n, nullptr, 0, 0.f, st)) return r;
+            continue;
+        }
         if (pk) { if (pgk_status r = pk_accum(attn, e->packed[l].o, QD, pk_so)) return r; }
         else if (pgk_status r = proj_accum(attn, L.w_o, L.s_o, H, QD, s_o)) return r;
         if (pgk_status r = norm((const bf16*)L.mlp_norm, fuse_q)) return r;

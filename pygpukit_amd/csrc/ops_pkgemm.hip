@@ -125,6 +125,21 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
         }
     }
 
+    // rows that arrive un-normalised (pkgemm_resid_nt): 1 / rms of this m-block's rows from the producer's partial sums,
+    // 8 threads per row; visible to everyone after the barrier that follows the DMA wait
+    __shared__ float inv_lds[PK_MB];
+    const bool scaled = g.ss_in != nullptr;
+    if (scaled) {
+        const int row = threadIdx.x >> 3, sub = threadIdx.x & 7;
+        const float* sp = g.ss_in + (size_t)min(m0 + row, g.M - 1) * PK_SS_LD + 8 * sub;   // a row's PK_SS_LD floats: 8 per thread, two 16-byte loads
+        const float4 u = *reinterpret_cast<const float4*>(sp), v = *reinterpret_cast<const float4*>(sp + 4);
+        const float p8[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+        float ssum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ssum += (8 * sub + i < g.ss_n) ? p8[i] : 0.f;
+        ssum = group8_sum(ssum);
+        if (sub == 0) inv_lds[row] = 1.0f / sqrtf(ssum / (float)g.K + g.ss_eps);
+    }
     // activation block by LDS-DMA: instruction j fills LDS bytes [1024 j, +1024) = four 256-byte swizzle groups; lane i sits
     // in group 4 j + (i >> 4) at chunk position i & 15.  row = group / groups-per-row through a 16-bit reciprocal (exact for
     // the <= 2048 groups of a block, no integer division in the issue path).
@@ -212,6 +227,16 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
     }
 
     PK_STAMP(4);
+    if (scaled) {
+#pragma unroll
+        for (int mt = 0; mt < PK_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float inv = inv_lds[mt * 16 + 4 * q + r];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[t][mt][r] *= inv;
+            }
+    }
     // C/D map: column (weight row) = l15 of the tile, row m = mt * 16 + 4 q + r
     if constexpr (EPI == PK_EPI_BF16 || EPI == PK_EPI_SLAB || EPI == PK_EPI_ACCUM) {
 #pragma unroll
@@ -331,6 +356,196 @@ extern "C" int pgk_debug_pk_stamps(unsigned long long* out) {   // [5][512][8]
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pk_stamps), sizeof(g_pk_stamps));
 }
 #endif
+
+// ---------------------------------------------------------------------------------------------------------------------
+// N = hidden projections WITHOUT a K split over workgroups: h += A . W^T with the next RMSNorm's inputs as by-products.
+// The split-K form above needs a reducer launch (the RMSNorm kernel sums the slabs): ~5 us + a dependent-launch gap, twice
+// per layer.  Here a workgroup owns NTW n-tiles x MB rows over the WHOLE K: its four waves take a K quarter each (a wave
+// reads only its quarter of the activation block from LDS), meet in LDS, and the workgroup adds the residual, stores
+// h_new, bf16(h_new * gamma_next) and the sum of squares of its columns per row.  The consumer (QKV / gate_up above)
+// multiplies with the un-normalised rows and scales its result rows by 1 / rms.  Costs more texture-addresser time per
+// workgroup than the split form (the activation block is MB x K instead of MB x K / splits) and saves the launch.
+struct PkResidArgs {
+    const bf16* a;
+    int lda;
+    const bf16* wp;
+    int M, N, K;
+    int nblk, mblk;
+    float* h;
+    const bf16* gamma_next;
+    bf16* xpre;
+    float* ss_out;
+    const float* ss_in;     // the rows in `a` may themselves be un-normalised... (not used by o_proj / down_proj: attention and
+    int ss_n;               // SwiGLU outputs are plain); kept for symmetry with PkArgs
+    float ss_eps;
+};
+
+template <int MB, int NTW>
+__global__ __launch_bounds__(PK_THREADS) void pkgemm_resid_kernel(PkResidArgs g) {
+    constexpr int MT = MB / 16, NC = 16 * NTW;
+    constexpr int EPT = MB * NC / PK_THREADS;                       // output elements per thread (1 or 2)
+    static_assert(MB * NC == 512 || MB * NC == 256, "one workgroup owns 32 x 16, 16 x 32 or 16 x 16 outputs");
+    extern __shared__ __attribute__((aligned(16))) char a_lds[];   // [MB][K] bf16, chunk-swizzled rows
+    __shared__ __attribute__((aligned(16))) float4 kpart[4 * NTW * MT * 64];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, q = lane >> 4;
+    int cb, mb;
+    {
+        const int per = 8 * g.mblk;
+        const int grp = blockIdx.x / per, r = blockIdx.x - grp * per;
+        cb = grp * 8 + (r & 7);
+        mb = r >> 3;
+        if (cb >= g.nblk) return;
+    }
+    const int m0 = mb * MB, n0 = cb * NC;
+    const int KS = g.K / 32, KSW = KS / 4, ksw0 = wid * KSW;       // this wave's k-steps
+    const int rb = KS * 64;
+    // the residual values of this thread's outputs first: they are needed last, and first in = first out
+    float hold[EPT];
+    int em[EPT], en[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = threadIdx.x + PK_THREADS * i;
+        em[i] = e / NC; en[i] = e % NC;
+        hold[i] = g.h[(size_t)min(m0 + em[i], g.M - 1) * g.N + n0 + en[i]];
+    }
+    float gnx[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) gnx[i] = g.gamma_next ? to_f(g.gamma_next[n0 + en[i]]) : 0.f;
+    {
+        const uint32_t lds0 = pk_lds_addr(a_lds);
+        const int ndma = MB * rb / 1024, gpr = KS >> 2;
+        const uint32_t magic = (65536u + gpr - 1) / gpr;
+        for (int j = wid; j < ndma; j += 4) {
+            const int grp = 4 * j + q;
+            const int row = (int)(((uint32_t)grp * magic) >> 16), gi = grp - row * gpr;
+            const int c = gi * 16 + ((l15 ^ row) & 15);
+            pk_dma16(g.a + (size_t)min(m0 + row, g.M - 1) * g.lda + c * 8, lds0 + j * 1024);
+        }
+    }
+    const int ksn = KS;
+    const bf16* wrun[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) wrun[t] = g.wp + ((size_t)(cb * NTW + t) * ksn + ksw0) * 512 + lane * 8;
+    uint4 wr[NTW][PK_RING];
+#pragma unroll
+    for (int s = 0; s < PK_RING; ++s)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) wr[t][s] = *reinterpret_cast<const uint4*>(wrun[t] + (size_t)min(s, KSW - 1) * 512);
+    if constexpr (NTW == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __syncthreads();
+
+    f32x4_p acc[NTW][MT];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4_p{0.f, 0.f, 0.f, 0.f};
+    uint4 af[4][MT];
+    int aoff[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aoff[mt][j] = (mt * 16 + l15) * rb + ((((4 * j + q) ^ l15) & 15) << 4);
+    auto read_a = [&](int ks, int j, uint4 (&dst)[MT]) {       // ks: k-step of the whole block; j == ks & 3
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) dst[mt] = *reinterpret_cast<const uint4*>(a_lds + aoff[mt][j] + ((ks >> 2) << 8));
+    };
+    auto step = [&](int s, const uint4 (&a_cur)[MT]) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const bf16x8_p b = __builtin_bit_cast(bf16x8_p, wr[t][s]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_p, a_cur[mt]), b, acc[t][mt], 0, 0, 0);
+        }
+    };
+    auto ahead = [&](int ks, int s2) {                          // local k-step ks, s2 = ks mod 16; KSW and ksw0 are multiples of 4
+        const int j = (s2 + 2) & 3;
+        read_a(ksw0 + min(ks + 2, KSW - 4 + j), j, af[(s2 + 2) & 3]);
+    };
+    read_a(ksw0, 0, af[0]);
+    read_a(ksw0 + 1, 1, af[1]);
+    const int nfull = KSW / PK_RING, rem = KSW % PK_RING;
+    for (int blk = 0; blk < nfull; ++blk) {
+#pragma unroll
+        for (int s = 0; s < PK_RING; ++s) {
+            const int ks = blk * PK_RING + s;
+            ahead(ks, s);
+            step(s, af[s & 3]);
+            if (ks + PK_RING < KSW) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) wr[t][s] = *reinterpret_cast<const uint4*>(wrun[t] + (size_t)(ks + PK_RING) * 512);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < PK_RING; ++s) {
+        if (s < rem) {
+            const int ks = nfull * PK_RING + s;
+            ahead(ks, s);
+            step(s, af[s & 3]);
+        }
+    }
+    // the four K quarters meet: [wave][tile][m-tile][lane] float4, then thread e sums its element's four partials
+    {
+        float4* mine = kpart + (size_t)wid * NTW * MT * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) mine[(t * MT + mt) * 64] = make_float4(acc[t][mt][0], acc[t][mt][1], acc[t][mt][2], acc[t][mt][3]);
+    }
+    __syncthreads();
+    const float* kp = reinterpret_cast<const float*>(kpart);
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int m = em[i], n = en[i];
+        // C/D map: tile n >> 4, column lane & 15 = n & 15, row = 4 (lane >> 4) + reg -> lane = 16 ((m & 15) >> 2) + (n & 15), reg = m & 3
+        const int idx = ((((n >> 4) * MT + (m >> 4)) * 64) + 16 * ((m & 15) >> 2) + (n & 15)) * 4 + (m & 3);
+        float v = hold[i];
+        v += (kp[idx] + kp[idx + NTW * MT * 256]) + (kp[idx + 2 * NTW * MT * 256] + kp[idx + 3 * NTW * MT * 256]);
+        const bool ok = m0 + m < g.M;
+        if (ok) g.h[(size_t)(m0 + m) * g.N + n0 + n] = v;
+        if (g.gamma_next) {
+            if (ok) g.xpre[(size_t)(m0 + m) * g.N + n0 + n] = from_f<bf16>(v * gnx[i]);
+            const float sq = group_sum<NC>(v * v);                 // the NC threads of a row are consecutive lanes
+            if (n == 0 && ok) g.ss_out[(size_t)(m0 + m) * PK_SS_LD + cb] = sq;
+        }
+    }
+}
+
+bool pkgemm_resid_ok(int N, int K) { return N % 32 == 0 && N / 16 <= PK_SS_LD && K % 512 == 0 && 16 * (K / 32) * 64 <= 128 * 1024; }
+
+pgk_status pkgemm_resid_nt(const bf16* a, int lda, const void* wp, float* h, int M, int N, int K, const bf16* gamma_next, bf16* xpre,
+                           float* ss_out, int* ss_n, const float* ss_in, int ss_in_n, float ss_eps, hipStream_t st) {
+    PGK_REQUIRE(M >= 1 && M <= 128 && pkgemm_resid_ok(N, K) && lda % 8 == 0, "pkgemm_resid: M=%d N=%d K=%d lda=%d not supported", M, N, K, lda);
+    PGK_REQUIRE(!gamma_next || (xpre && ss_out && ss_n), "pkgemm_resid: the next norm's outputs are missing");
+    PkResidArgs g{a, lda, (const bf16*)wp, M, N, K, 0, 0, h, gamma_next, xpre, ss_out, ss_in, ss_in_n, ss_eps};
+    // 16 rows x one n-tile while that still leaves at most one workgroup per CU (fewest bytes per workgroup); otherwise
+    // 32 rows x one n-tile while the 32-row activation block fits the LDS budget, else 16 rows x two n-tiles
+    const bool small = (N / 16) * ceil_div(M, 16) <= 256;
+    const bool wide = !small && (size_t)32 * (K / 32) * 64 <= 128 * 1024;
+    const int mb = wide ? 32 : 16, ntw = (small || wide) ? 1 : 2;
+    g.nblk = N / (16 * ntw);
+    g.mblk = ceil_div(M, mb);
+    if (ss_n) *ss_n = g.nblk;
+    const size_t lds = (size_t)mb * (K / 32) * 64;
+    const int grid = ceil_div(g.nblk, 8) * 8 * g.mblk;
+#define PGK_PKR_LAUNCH(MBV, NTWV)                                                                                  \
+    {                                                                                                              \
+        static bool attr = false;                                                                                  \
+        if (lds > 48 * 1024 && !attr) {                                                                            \
+            PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pkgemm_resid_kernel<MBV, NTWV>),       \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));     \
+            attr = true;                                                                                           \
+        }                                                                                                          \
+        pkgemm_resid_kernel<MBV, NTWV><<<grid, PK_THREADS, lds, st>>>(g);                                          \
+    }
+    if (small) PGK_PKR_LAUNCH(16, 1) else if (wide) PGK_PKR_LAUNCH(32, 1) else PGK_PKR_LAUNCH(16, 2)
+#undef PGK_PKR_LAUNCH
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
+}
 
 // K splits for the N = hidden projections: enough workgroups to cover the chip, and a K range per workgroup whose
 // activation block (32 rows) fits the LDS budget.  0: no split count works for this K.

@@ -157,6 +157,13 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
                     for (int j = 0; j < KJ; ++j)
 #pragma unroll
                         for (int p = 0; p < NP; ++p) hv[m][j] += (p < np) ? pvs[m][j][p] : 0.f;
+                // more than NP partial vectors (models with more than 8 kv heads): the rest in a second trip.  (Until this loop
+                // existed partials 8.. were silently dropped: batch-1 / batch-2 decode of a 16-kv-head model was wrong.)
+                for (int p = NP; p < np; ++p)
+#pragma unroll
+                    for (int m = 0; m < M; ++m)
+#pragma unroll
+                        for (int j = 0; j < KJ; ++j) hv[m][j] += ld_act(a.part + ((size_t)m * np + p) * KC + threadIdx.x + 256 * j, coh);
             }
             float ss[M];
 #pragma unroll
@@ -893,6 +900,290 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a, unsigned lo
     tls.end();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused batch-1 attention + o_proj with both products on the matrix pipe (head_dim 128).
+//
+// attn_oproj_kernel above spends 2.1 of its 5.5 us in the score / P.V loop: one wave per SIMD, ~750 VALU instructions per 48
+// positions (v_dot2c at ~10 cycles of issue, DPP reductions).  The first attempt to move Q.K^T to MFMA loaded the K rows
+// from global memory in A-fragment shape (lane = row): 64 separate 16-byte pieces per instruction, and the kernel lost
+// more in its load issue phase than the MFMAs won.  Here the cached rows are staged ROW-MAJOR by LDS-DMA -
+// the same bytes per instruction as the register loads they replace, 1 KiB contiguous each - and the fragments come out
+// of LDS: the one-tile prefill kernel's scheme (ops_attention.hip, attn_short_kernel) with the G query heads of the kv
+// head as the only live columns:
+//   * chunks of 192 positions: K and V rows [c0, c0 + 192) -> LDS (K: 16-byte chunks XOR row & 15; V: layout (b) of the
+//     CDNA guide for ds_read_b64_tr_b16); chunk 0 is requested before the position is known (clamped rows);
+//   * wave w takes tiles w, w + 4, w + 8 of the chunk (16 positions each): S^T = K.Q^T - rows = positions, columns =
+//     heads - so a lane holds ONE head's scores of 4 consecutive positions per tile; max / sum are lane-local + two
+//     shuffles; exp'd and packed to bf16 they are the B operand of O^T = V^T.P^T with no LDS round trip (k-slot j of lane
+//     quarter q <-> position 16 tile(j >> 2) + 4 q + (j & 3), V read with the same slots through the transposing read);
+//   * every wave keeps a running (m, l, O^T) across chunks; at the end the four waves' states and the new token's
+//     (score, 1, v) meet in LDS and are combined per output element, then the W_o slice product as before.
+// The new token's k/v never enter the LDS images (the DMA of its cache row would race the write): it is a fifth partial.
+constexpr int AM_CHUNK = 192;   // positions per staged chunk: 12 tiles, 3 per wave
+
+__device__ __forceinline__ int am_koff(int row, int ch) { return row * 256 + ((ch ^ (row & 15)) << 4); }
+__device__ __forceinline__ int am_voff(int row, int ch) { return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
+
+template <int G>
+__global__ __launch_bounds__(256) void attn_oproj_mfma_kernel(AttnArgs a, unsigned long long* tl) {
+    const TLStamp tls(tl);
+    typedef __bf16 am_bf16x8 __attribute__((ext_vector_type(8)));
+    typedef float am_f32x4 __attribute__((ext_vector_type(4)));
+    typedef short am_v4s __attribute__((ext_vector_type(4)));
+    constexpr int D = 128, NWV = 4, LPR = 16, RS = D + 4;   // a state record: o[128], then m, l (16-byte aligned rows)
+    constexpr int GD = G * D, LPW = GD / 8, RPP = NWV * 64 / LPW, PRE = 4;
+    extern __shared__ __attribute__((aligned(16))) char am_lds[];          // K image | V image (AM_CHUNK rows x 256 bytes each)
+    char* k_lds = am_lds;
+    char* v_lds = am_lds + AM_CHUNK * 256;
+    __shared__ __attribute__((aligned(16))) uint4 q_lds[NWV][G][16];       // per wave: the heads' q as 16 chunks of 8 dims
+    __shared__ __attribute__((aligned(16))) float part[NWV + 1][G][RS];    // (o[128], m, l) of the four waves + the new token
+    __shared__ __attribute__((aligned(16))) float attn[GD];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int kvh = blockIdx.x % a.hkv, rb = blockIdx.x / a.hkv, b = blockIdx.z;   // kv head fastest: XCD-aware (attn_oproj_kernel)
+    const int r0 = rb * a.rows_per_block;
+    const int lr = threadIdx.x % LPW, rip = threadIdx.x / LPW;
+    const int npass = a.rows_per_block / RPP;
+    const bf16* wbase = a.w_o + (size_t)kvh * GD + lr * 8;
+    const int ldw = a.hq * D;
+    const size_t head_off = (((size_t)b * a.hkv + kvh) * a.max_seq) * D;
+    const bf16* kc = a.kcache + head_off;
+    const bf16* vc = a.vcache + head_off;
+
+    // Issue order = arrival order, and every wait on it is written out here: the new token's inputs, the cache chunk and
+    // nothing else go through LDS-DMA issued as inline asm, so the compiler neither counts them nor - as it does for the
+    // builtin form - answers any vector load older than them with vmcnt(0) (which made the norm / RoPE work wait for
+    // the whole chunk).  Per wave: NRAW instructions for ITS copy of the new token's fp32 q/k/v slices, the two gammas
+    // and the RoPE row (3 KiB for G = 2: three instructions instead of 14 register loads), 24 for the chunk, then the four
+    // W_o preloads as ordinary loads.
+    auto dma = [](const void* src, uint32_t lds_addr) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+    };
+    auto lds_u32 = [](const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; };
+    constexpr int HB = (G + 2) * 512;                     // bytes of the head slices in a wave's slot; then gq, gk, cos, sin (256 each)
+    constexpr int NRAW = (HB + 1024 + 1023) / 1024;
+    __shared__ __attribute__((aligned(16))) char raw_lds[NWV][NRAW * 1024];
+    {
+        const char* row = reinterpret_cast<const char*>(a.qkv + (size_t)b * a.qkv_ld);
+        const char* cosr = reinterpret_cast<const char*>(a.rope_cos + (size_t)b * 64);
+        const char* sinr = reinterpret_cast<const char*>(a.rope_sin + (size_t)b * 64);
+        const char* gqp = a.q_gamma ? reinterpret_cast<const char*>(a.q_gamma) : cosr;      // no QK-norm: any valid bytes
+        const char* gkp = a.k_gamma ? reinterpret_cast<const char*>(a.k_gamma) : cosr;
+#pragma unroll
+        for (int i = 0; i < NRAW; ++i) {
+            const int o = 1024 * i + 16 * lane;
+            const char* src;
+            if (o < HB) {
+                const int hs = o >> 9, within = o & 511;
+                const int elem = (hs < G) ? (kvh * a.g_total + a.g_off + hs) * D : (hs == G ? (a.hq + kvh) * D : (a.hq + a.hkv + kvh) * D);
+                src = row + (size_t)elem * 4 + within;
+            } else {
+                const int o2 = min(o - HB, 1023), seg = o2 >> 8, within = o2 & 255;
+                src = (seg == 0 ? gqp : seg == 1 ? gkp : seg == 2 ? cosr : sinr) + within;
+            }
+            dma(src, lds_u32(&raw_lds[wid][0]) + 1024 * i);
+        }
+    }
+    auto stage = [&](int c0) {      // rows [c0, c0 + AM_CHUNK) of K and V: instruction j = 4 rows, lane i -> row 4 j + (i >> 4), chunk position i & 15
+#pragma unroll
+        for (int i = 0; i < AM_CHUNK / 4 / NWV; ++i) {
+            const int j = wid + NWV * i;
+            const int rl = 4 * j + q4, rg = min(c0 + rl, a.max_seq - 1);
+            dma(kc + (size_t)rg * D + ((l15 ^ (rl & 15)) << 3), lds_u32(k_lds) + j * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < AM_CHUNK / 4 / NWV; ++i) {
+            const int j = wid + NWV * i;
+            const int rl = 4 * j + q4, rg = min(c0 + rl, a.max_seq - 1);
+            dma(vc + (size_t)rg * D + ((l15 ^ (((rl & 3) << 2) | ((rl >> 2) & 3))) << 3), lds_u32(v_lds) + j * 1024);
+        }
+    };
+    stage(0);
+    uint4 pre[PRE];
+#pragma unroll
+    for (int p = 0; p < PRE; ++p) pre[p] = load_nt16(wbase + (size_t)(r0 + min(p, npass - 1) * RPP + rip) * ldw);
+    __builtin_amdgcn_sched_barrier(0);
+    const int pos = load_uniform_i32(a.positions + b);
+    tls.phase(0);
+    static_assert(2 * (AM_CHUNK / 4 / NWV) + PRE == 28, "the wait below counts the vector-memory operations issued after the new token's DMAs");
+    asm volatile("s_waitcnt vmcnt(28)" ::: "memory");      // in-order return: this wave's copy of the new token's inputs is in its slot
+    NewTokenRaw<G> raw;
+    {
+        const char* slot = &raw_lds[wid][0];
+#pragma unroll
+        for (int g = 0; g < G + 2; ++g) {
+            raw.lo[g] = *reinterpret_cast<const float4*>(slot + g * 512 + l15 * 32);
+            raw.hi[g] = *reinterpret_cast<const float4*>(slot + g * 512 + l15 * 32 + 16);
+        }
+        raw.gq = raw.gk = make_uint4(0, 0, 0, 0);
+        if (a.q_gamma != nullptr) {
+            raw.gq = *reinterpret_cast<const uint4*>(slot + HB + l15 * 16);
+            raw.gk = *reinterpret_cast<const uint4*>(slot + HB + 256 + l15 * 16);
+        }
+        const int dd = (l15 * 8) % 64;
+        raw.cs[0] = *reinterpret_cast<const float4*>(slot + HB + 512 + dd * 4); raw.cs[1] = *reinterpret_cast<const float4*>(slot + HB + 512 + dd * 4 + 16);
+        raw.sn[0] = *reinterpret_cast<const float4*>(slot + HB + 768 + dd * 4); raw.sn[1] = *reinterpret_cast<const float4*>(slot + HB + 768 + dd * 4 + 16);
+    }
+    NewToken<D, G> t;
+    new_token_finish<D, G>(a, lane, raw, t);
+    if (rb == 0 && pos < a.max_seq && wid == 0 && lane < LPR) {
+        *reinterpret_cast<uint4*>(a.kcache + head_off + (size_t)pos * D + l15 * 8) = t.kbits;
+        *reinterpret_cast<uint4*>(a.vcache + head_off + (size_t)pos * D + l15 * 8) = t.vbits;
+    }
+    // q as B fragments: lane (l15 = head, q4) of k-step ks needs dims 32 ks + 8 q4 .. + 8 of head l15; every lane holds chunk
+    // l15 of all heads - one trip through this wave's own LDS slot
+    if (lane < 16) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) q_lds[wid][g][lane] = t.qb[g];
+    }
+    // the new token as the fifth partial (wave 0): score = q . k_new per head, weight 1, value v_new
+    if (wid == 0 && lane < LPR) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float dsum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dsum = fmaf(t.qf[g][j], t.kn[j], dsum);
+            dsum = group_sum<LPR>(dsum);
+            const bool live = pos < a.max_seq;
+            if (lane == 0) { part[NWV][g][D] = live ? dsum : -INFINITY; part[NWV][g][D + 1] = live ? 1.f : 0.f; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[NWV][g][lane * 8 + j] = t.vn[j];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint4 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 v = q_lds[wid][min(l15, G - 1)][4 * ks + q4];
+        qf[ks] = l15 < G ? v : make_uint4(0, 0, 0, 0);
+    }
+    tls.phase(1);
+    const int c1 = min(pos, a.max_seq);                 // cached positions [0, c1)
+    float m_run = -INFINITY, l_run = 0.f;                // of head l15 (lanes l15 >= G carry dummies)
+    am_f32x4 o[D / 16];
+#pragma unroll
+    for (int i = 0; i < D / 16; ++i) o[i] = am_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tq = l15 >> 2, tp = l15 & 3;
+    for (int c0 = 0; c0 == 0 || c0 < c1; c0 += AM_CHUNK) {
+        if (c0 > 0) {
+            __syncthreads();                               // everyone is done with the previous chunk's images
+            stage(c0);
+        }
+        // chunk 0: everything but what was issued behind it - the four W_o preloads and, in the one wave that stored the new
+        // token's cache row, those two stores (stores count in vmcnt on gfx9)
+        if (c0 > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (rb == 0 && pos < a.max_seq && wid == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __syncthreads();
+        // S^T tiles of this wave: rows = positions c0 + 16 t + 4 q4 + r, column = head l15
+        am_f32x4 s[3];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int tile = wid + NWV * u;
+            s[u] = am_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c0 + 16 * tile < c1) {                     // wave-uniform
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const uint4 ka = *reinterpret_cast<const uint4*>(k_lds + am_koff(16 * tile + l15, 4 * ks + q4));
+                    s[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(am_bf16x8, ka), __builtin_bit_cast(am_bf16x8, qf[ks]), s[u], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = c0 + 16 * tile + 4 * q4 + r < c1;
+                s[u][r] = ok ? s[u][r] : -INFINITY;
+                mx = fmaxf(mx, s[u][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
+        float ls = 0.f;
+        uint32_t pk[3][2];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = (m_new == -INFINITY) ? 0.f : __expf(s[u][r] - m_new);
+            pk[u][0] = pack_bf16x2(p[0], p[1]);
+            pk[u][1] = pack_bf16x2(p[2], p[3]);
+            ls += (__uint_as_float(pk[u][0] << 16) + __uint_as_float(pk[u][0] & 0xFFFF0000u)) + (__uint_as_float(pk[u][1] << 16) + __uint_as_float(pk[u][1] & 0xFFFF0000u));
+        }
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < D / 16; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[i][r] *= alpha;
+        // O^T += V^T . P^T: step 0 pairs tiles (wid, wid + 4), step 1 tile wid + 8 with zeros
+#pragma unroll
+        for (int st2 = 0; st2 < 2; ++st2) {
+            const int ta = wid + NWV * (2 * st2), tb = (st2 == 0) ? wid + NWV : ta;     // tb of step 1: any staged tile (weights zero)
+            if (c0 + 16 * ta < c1) {                       // wave-uniform
+                const uint4 pf = make_uint4(pk[2 * st2][0], pk[2 * st2][1], st2 == 0 ? pk[1][0] : 0u, st2 == 0 ? pk[1][1] : 0u);
+                const int ra = 16 * ta + 4 * q4 + tq, rbv = 16 * tb + 4 * q4 + tq;
+#pragma unroll
+                for (int i = 0; i < D / 16; ++i) {
+                    const am_v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) am_v4s*)(v_lds + am_voff(ra, 2 * i + (tp >> 1)) + 8 * (tp & 1)));
+                    const am_v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) am_v4s*)(v_lds + am_voff(rbv, 2 * i + (tp >> 1)) + 8 * (tp & 1)));
+                    const uint2 u0 = __builtin_bit_cast(uint2, a0), u1 = __builtin_bit_cast(uint2, a1);
+                    const uint4 va = make_uint4(u0.x, u0.y, u1.x, u1.y);
+                    o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(am_bf16x8, va), __builtin_bit_cast(am_bf16x8, pf), o[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    tls.phase(2);
+    // the waves' states -> LDS: lane (l15 = head g, q4) holds dims 16 i + 4 q4 + r of head g
+    if (l15 < G) {
+        if (q4 == 0) { part[wid][l15][D] = m_run; part[wid][l15][D + 1] = l_run; }
+#pragma unroll
+        for (int i = 0; i < D / 16; ++i)
+            *reinterpret_cast<float4*>(&part[wid][l15][16 * i + 4 * q4]) = make_float4(o[i][0], o[i][1], o[i][2], o[i][3]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < GD; e += 256) {
+        const int g = e / D, d = e % D;
+        float mstar = -INFINITY;
+#pragma unroll
+        for (int w = 0; w <= NWV; ++w) mstar = fmaxf(mstar, part[w][g][D]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w <= NWV; ++w) {
+            const float mw = part[w][g][D];
+            const float wgt = (mw == -INFINITY) ? 0.f : __expf(mw - mstar);
+            num = fmaf(wgt, part[w][g][d], num);
+            den = fmaf(wgt, part[w][g][D + 1], den);
+        }
+        attn[e] = den > 0.f ? num / den : 0.f;
+    }
+    __syncthreads();
+    tls.phase(3);
+    float xf[8];
+    {
+        const float4 u = *reinterpret_cast<const float4*>(attn + lr * 8), v = *reinterpret_cast<const float4*>(attn + lr * 8 + 4);
+        xf[0] = u.x; xf[1] = u.y; xf[2] = u.z; xf[3] = u.w; xf[4] = v.x; xf[5] = v.y; xf[6] = v.z; xf[7] = v.w;
+    }
+    float* outp = a.opart + ((size_t)b * a.hkv + kvh) * a.H;
+    for (int p = 0; p < npass; ++p) {
+        const int row = r0 + p * RPP + rip;
+        uint4 w = (p < PRE) ? pre[p < PRE ? p : 0] : load_nt16(wbase + (size_t)row * ldw);
+        float wf[8];
+        WTraits<bf16>::decode(w, wf);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf(wf[j], xf[j], acc);
+        acc = group_sum<LPW>(acc);
+        if (lr == 0) outp[row] = acc;
+    }
+    tls.phase(4);
+    tls.end();
+}
+
 // long-context path, steps 2 + 3 in ONE launch: merge the split-KV records of a kv head's G query heads (the arithmetic
 // of attn_merge_kernel, same order) and multiply the result with this workgroup's slice of W_o.  Grid as attn_oproj_kernel
 // ((H / rows_per_block) * Hkv, kv head fastest: XCD-aware), output the same per-kv-head partial vectors, which the
@@ -1243,6 +1534,7 @@ struct Engine {
     static constexpr int skip_attn = 0;
 #endif
     bool fused_attn = false;   // attn + o_proj in one kernel (short contexts, bf16 W_o)
+    bool attn_mfma = false;    // ... with Q.K^T and P.V on the matrix pipe from LDS-staged K/V (head_dim 128; PGK_ATTN_MFMA=0: the dot2 kernel)
     bool merged_oproj = false; // long contexts / fp8 W_o, one or two sequences: split-KV merge + o_proj in one kernel (PGK_MERGED_OPROJ=0: merge kernel + GEMV)
     int moproj_rows = 32;
     int oproj_rows = 32;       // W_o rows per workgroup on the fused path
@@ -1360,6 +1652,18 @@ static int gqa_chunks(int G) {
     return n;
 }
 
+template <int G>
+static hipError_t launch_attn_mfma(dim3 grid, hipStream_t st, const AttnArgs& a) {
+    constexpr int lds = 2 * AM_CHUNK * 256;
+    static bool attr = false;
+    if (!attr) {
+        const hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_oproj_mfma_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (he != hipSuccess) return he;
+        attr = true;
+    }
+    return launch_k(attn_oproj_mfma_kernel<G>, grid, dim3(256), lds, st, a);
+}
+
 template <int D>
 static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, hipStream_t st, bool direct_bf16 = false,
                               const DepArgs* dep = nullptr, bool merged = false) {
@@ -1422,6 +1726,7 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
 #define PGK_ATTN(GG)                                                               \
     case GG:                                                                       \
         if (fused && a.dep.sig_cnt) he = launch_k(attn_oproj_kernel<D, GG, true>, grid, dim3(256), 0, st, a);   \
+        else if (fused && D == 128 && e->attn_mfma) he = launch_attn_mfma<GG>(grid, st, a);         \
         else if (fused) he = launch_k(attn_oproj_kernel<D, GG, false>, grid, dim3(256), 0, st, a);  \
         else if (direct) he = launch_k(attn_decode_kernel<D, GG, true>, grid, dim3(256), 0, st, a); \
         else he = launch_k(attn_decode_kernel<D, GG, false>, grid, dim3(256), 0, st, a);            \
@@ -1872,6 +2177,10 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         const bool want = env ? atoi(env) != 0 : true;
         e->fused_attn = want && tiles && c.weight_format == 0 && c.max_seq_len <= 512 && (G == 1 || G == 2 || G == 4);
         e->oproj_rows = rows;
+        {
+            const char* am = getenv("PGK_ATTN_MFMA");
+            e->attn_mfma = e->fused_attn && c.head_dim == 128 && !(am && atoi(am) == 0);
+        }
         // merged o_proj (long contexts, fp8 W_o): same slicing rule with 16 codes per lane for fp8
         const int nwt = c.weight_format != 0 ? 16 : 8, lpw = gd / nwt, rpp2 = lpw > 0 ? 256 / lpw : 256;
         int rows2 = c.hidden_size / 32;

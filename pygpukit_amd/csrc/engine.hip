@@ -935,7 +935,6 @@ __global__ __launch_bounds__(256) void attn_oproj_mfma_kernel(AttnArgs a, unsign
     extern __shared__ __attribute__((aligned(16))) char am_lds[];          // K image | V image (AM_CHUNK rows x 256 bytes each)
     char* k_lds = am_lds;
     char* v_lds = am_lds + AM_CHUNK * 256;
-    __shared__ __attribute__((aligned(16))) uint4 q_lds[NWV][G][16];       // per wave: the heads' q as 16 chunks of 8 dims
     __shared__ __attribute__((aligned(16))) float part[NWV + 1][G][RS];    // (o[128], m, l) of the four waves + the new token
     __shared__ __attribute__((aligned(16))) float attn[GD];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1007,57 +1006,58 @@ __global__ __launch_bounds__(256) void attn_oproj_mfma_kernel(AttnArgs a, unsign
     tls.phase(0);
     static_assert(2 * (AM_CHUNK / 4 / NWV) + PRE == 28, "the wait below counts the vector-memory operations issued after the new token's DMAs");
     asm volatile("s_waitcnt vmcnt(28)" ::: "memory");      // in-order return: this wave's copy of the new token's inputs is in its slot
-    NewTokenRaw<G> raw;
+    // The new token's G + 2 head vectors (q heads, k, v) are SPLIT over the waves - item i goes to wave i % 4 - instead of
+    // every wave normalising and rotating all of them (0.74 us of ALU per wave in attn_oproj_kernel): each wave reads its
+    // item from its own copy of the inputs, and the results meet in LDS behind the barrier that the cache chunk needs anyway.
+    __shared__ __attribute__((aligned(16))) uint4 q_sh[G][16], k_sh[16], v_sh[16];   // bf16, 16 chunks of 8 dims per vector
     {
         const char* slot = &raw_lds[wid][0];
-#pragma unroll
-        for (int g = 0; g < G + 2; ++g) {
-            raw.lo[g] = *reinterpret_cast<const float4*>(slot + g * 512 + l15 * 32);
-            raw.hi[g] = *reinterpret_cast<const float4*>(slot + g * 512 + l15 * 32 + 16);
+        const int sub = l15;                                 // the lane's 8 dims: sub * 8 .. + 8 (all four lane quarters compute the same)
+        const int dd = (sub * 8) % 64;
+        float csv[8], snv[8];
+        {
+            const float4 c0v = *reinterpret_cast<const float4*>(slot + HB + 512 + dd * 4), c1v = *reinterpret_cast<const float4*>(slot + HB + 512 + dd * 4 + 16);
+            const float4 s0v = *reinterpret_cast<const float4*>(slot + HB + 768 + dd * 4), s1v = *reinterpret_cast<const float4*>(slot + HB + 768 + dd * 4 + 16);
+            csv[0] = c0v.x; csv[1] = c0v.y; csv[2] = c0v.z; csv[3] = c0v.w; csv[4] = c1v.x; csv[5] = c1v.y; csv[6] = c1v.z; csv[7] = c1v.w;
+            snv[0] = s0v.x; snv[1] = s0v.y; snv[2] = s0v.z; snv[3] = s0v.w; snv[4] = s1v.x; snv[5] = s1v.y; snv[6] = s1v.z; snv[7] = s1v.w;
         }
-        raw.gq = raw.gk = make_uint4(0, 0, 0, 0);
-        if (a.q_gamma != nullptr) {
-            raw.gq = *reinterpret_cast<const uint4*>(slot + HB + l15 * 16);
-            raw.gk = *reinterpret_cast<const uint4*>(slot + HB + 256 + l15 * 16);
+        const bool has_norm = a.q_gamma != nullptr;
+        for (int item = wid; item < G + 2; item += NWV) {    // wave-uniform
+            const float4 lo = *reinterpret_cast<const float4*>(slot + item * 512 + sub * 32), hi = *reinterpret_cast<const float4*>(slot + item * 512 + sub * 32 + 16);
+            float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            if (item < G + 1) {                              // q heads and k: QK-norm (optional) + RoPE, the arithmetic of new_token_finish
+                if (has_norm) {
+                    float gm[8];
+                    WTraits<bf16>::decode(*reinterpret_cast<const uint4*>(slot + HB + (item < G ? 0 : 256) + sub * 16), gm);
+                    float ss = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss = fmaf(x[j], x[j], ss);
+                    ss = group_sum<LPR>(ss);
+                    const float inv = 1.0f / sqrtf(ss / D + a.eps);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = x[j] * inv * gm[j];
+                }
+                const bool lo_half = sub < LPR / 2;
+                float o8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float other = xor_half<LPR>(x[j]);
+                    o8[j] = lo_half ? (x[j] * csv[j] - other * snv[j]) : (x[j] * csv[j] + other * snv[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = (item < G) ? o8[j] * a.scale : o8[j];
+            }
+            Vec<bf16> vb;
+            vb.from_float(x);
+            if (lane < 16) {
+                if (item < G) q_sh[item][lane] = vb.raw;
+                else if (item == G) k_sh[lane] = vb.raw;
+                else v_sh[lane] = vb.raw;
+            }
         }
-        const int dd = (l15 * 8) % 64;
-        raw.cs[0] = *reinterpret_cast<const float4*>(slot + HB + 512 + dd * 4); raw.cs[1] = *reinterpret_cast<const float4*>(slot + HB + 512 + dd * 4 + 16);
-        raw.sn[0] = *reinterpret_cast<const float4*>(slot + HB + 768 + dd * 4); raw.sn[1] = *reinterpret_cast<const float4*>(slot + HB + 768 + dd * 4 + 16);
-    }
-    NewToken<D, G> t;
-    new_token_finish<D, G>(a, lane, raw, t);
-    if (rb == 0 && pos < a.max_seq && wid == 0 && lane < LPR) {
-        *reinterpret_cast<uint4*>(a.kcache + head_off + (size_t)pos * D + l15 * 8) = t.kbits;
-        *reinterpret_cast<uint4*>(a.vcache + head_off + (size_t)pos * D + l15 * 8) = t.vbits;
-    }
-    // q as B fragments: lane (l15 = head, q4) of k-step ks needs dims 32 ks + 8 q4 .. + 8 of head l15; every lane holds chunk
-    // l15 of all heads - one trip through this wave's own LDS slot
-    if (lane < 16) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) q_lds[wid][g][lane] = t.qb[g];
-    }
-    // the new token as the fifth partial (wave 0): score = q . k_new per head, weight 1, value v_new
-    if (wid == 0 && lane < LPR) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float dsum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dsum = fmaf(t.qf[g][j], t.kn[j], dsum);
-            dsum = group_sum<LPR>(dsum);
-            const bool live = pos < a.max_seq;
-            if (lane == 0) { part[NWV][g][D] = live ? dsum : -INFINITY; part[NWV][g][D + 1] = live ? 1.f : 0.f; }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) part[NWV][g][lane * 8 + j] = t.vn[j];
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    uint4 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const uint4 v = q_lds[wid][min(l15, G - 1)][4 * ks + q4];
-        qf[ks] = l15 < G ? v : make_uint4(0, 0, 0, 0);
     }
     tls.phase(1);
+    uint4 qf[4];
     const int c1 = min(pos, a.max_seq);                 // cached positions [0, c1)
     float m_run = -INFINITY, l_run = 0.f;                // of head l15 (lanes l15 >= G carry dummies)
     am_f32x4 o[D / 16];
@@ -1069,12 +1069,45 @@ __global__ __launch_bounds__(256) void attn_oproj_mfma_kernel(AttnArgs a, unsign
             __syncthreads();                               // everyone is done with the previous chunk's images
             stage(c0);
         }
-        // chunk 0: everything but what was issued behind it - the four W_o preloads and, in the one wave that stored the new
-        // token's cache row, those two stores (stores count in vmcnt on gfx9)
+        // chunk 0: everything but the four W_o preloads issued behind it
         if (c0 > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (rb == 0 && pos < a.max_seq && wid == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __syncthreads();
+        if (c0 == 0) {
+            // q as B fragments: lane (l15 = head, q4) of k-step ks holds dims 32 ks + 8 q4 .. + 8 of head l15
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 v = q_sh[min(l15, G - 1)][4 * ks + q4];
+                qf[ks] = l15 < G ? v : make_uint4(0, 0, 0, 0);
+            }
+            // the new token: fifth partial (score = q . k_new per head, weight 1, value v_new) and its cache row - the last wave,
+            // which had the fewest items above
+            if (wid == NWV - 1 && lane < LPR) {
+                float kn[8], vn[8];
+                Vec<bf16> kb, vb2;
+                kb.raw = k_sh[lane]; vb2.raw = v_sh[lane];
+                kb.to_float(kn); vb2.to_float(vn);
+                const bool live = pos < a.max_seq;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    Vec<bf16> qb;
+                    qb.raw = q_sh[g][lane];
+                    float qv[8];
+                    qb.to_float(qv);
+                    float dsum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dsum = fmaf(qv[j], kn[j], dsum);
+                    dsum = group_sum<LPR>(dsum);
+                    if (lane == 0) { part[NWV][g][D] = live ? dsum : -INFINITY; part[NWV][g][D + 1] = live ? 1.f : 0.f; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) part[NWV][g][lane * 8 + j] = vn[j];
+                }
+                if (rb == 0 && live) {
+                    *reinterpret_cast<uint4*>(a.kcache + head_off + (size_t)pos * D + lane * 8) = kb.raw;
+                    *reinterpret_cast<uint4*>(a.vcache + head_off + (size_t)pos * D + lane * 8) = vb2.raw;
+                }
+            }
+        }
         // S^T tiles of this wave: rows = positions c0 + 16 t + 4 q4 + r, column = head l15
         am_f32x4 s[3];
         float mx = -INFINITY;

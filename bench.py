@@ -292,7 +292,7 @@ def main() -> None:
     rows = []
     kb = kernel_bytes_per_launch(cfg, ctx_mid, B)
     NAMES = {"norm_qkv": "fused_gemv_kernel<PRO_NORM, EPI_STORE> (RMSNorm + qkv projection)",
-             "attn": "attn_oproj_kernel (QK-norm, RoPE, KV write, attention, o_proj partials)",
+             "attn": "attn_oproj_mfma_kernel (QK-norm, RoPE, KV write, attention on MFMA from LDS-staged K/V, o_proj partials; attn_oproj_kernel when head_dim != 128)",
              "oproj": "fused_gemv_kernel<PRO_PLAIN, EPI_RESID> (o_proj + residual)",
              "gateup": "fused_gemv_kernel<PRO_NORM_SUM, EPI_SWIGLU> (residual sum + RMSNorm + gate/up + SwiGLU)",
              "down": "fused_gemv_kernel<PRO_PLAIN, EPI_RESID> (down projection + residual)",

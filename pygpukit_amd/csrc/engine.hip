@@ -924,14 +924,16 @@ constexpr int AM_CHUNK = 192;   // positions per staged chunk: 12 tiles, 3 per w
 __device__ __forceinline__ int am_koff(int row, int ch) { return row * 256 + ((ch ^ (row & 15)) << 4); }
 __device__ __forceinline__ int am_voff(int row, int ch) { return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
 
-template <int G>
+// OPROJ = false: the whole-context BATCH attention (one workgroup per (sequence, kv head), grid (Hkv, 1, batch)): the same
+// kernel without the W_o slice - the normalised heads leave as bf16 (attn_direct16) or fp32 (attn_direct) rows.
+template <int G, bool OPROJ = true>
 __global__ __launch_bounds__(256) void attn_oproj_mfma_kernel(AttnArgs a, unsigned long long* tl) {
     const TLStamp tls(tl);
     typedef __bf16 am_bf16x8 __attribute__((ext_vector_type(8)));
     typedef float am_f32x4 __attribute__((ext_vector_type(4)));
     typedef short am_v4s __attribute__((ext_vector_type(4)));
     constexpr int D = 128, NWV = 4, LPR = 16, RS = D + 4;   // a state record: o[128], then m, l (16-byte aligned rows)
-    constexpr int GD = G * D, LPW = GD / 8, RPP = NWV * 64 / LPW, PRE = 4;
+    constexpr int GD = G * D, LPW = GD / 8, RPP = NWV * 64 / LPW, PRE = OPROJ ? 4 : 0;
     extern __shared__ __attribute__((aligned(16))) char am_lds[];          // K image | V image (AM_CHUNK rows x 256 bytes each)
     char* k_lds = am_lds;
     char* v_lds = am_lds + AM_CHUNK * 256;
@@ -998,14 +1000,14 @@ __global__ __launch_bounds__(256) void attn_oproj_mfma_kernel(AttnArgs a, unsign
         }
     };
     stage(0);
-    uint4 pre[PRE];
+    uint4 pre[PRE > 0 ? PRE : 1];
 #pragma unroll
     for (int p = 0; p < PRE; ++p) pre[p] = load_nt16(wbase + (size_t)(r0 + min(p, npass - 1) * RPP + rip) * ldw);
     __builtin_amdgcn_sched_barrier(0);
     const int pos = load_uniform_i32(a.positions + b);
     tls.phase(0);
-    static_assert(2 * (AM_CHUNK / 4 / NWV) + PRE == 28, "the wait below counts the vector-memory operations issued after the new token's DMAs");
-    asm volatile("s_waitcnt vmcnt(28)" ::: "memory");      // in-order return: this wave's copy of the new token's inputs is in its slot
+    // in-order return: once at most the operations issued after them are outstanding, this wave's copy of the new token's inputs is in its slot
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AM_CHUNK / 4 / NWV) + PRE) : "memory");
     // The new token's G + 2 head vectors (q heads, k, v) are SPLIT over the waves - item i goes to wave i % 4 - instead of
     // every wave normalising and rotating all of them (0.74 us of ALU per wave in attn_oproj_kernel): each wave reads its
     // item from its own copy of the inputs, and the results meet in LDS behind the barrier that the cache chunk needs anyway.
@@ -1071,7 +1073,7 @@ __global__ __launch_bounds__(256) void attn_oproj_mfma_kernel(AttnArgs a, unsign
         }
         // chunk 0: everything but the four W_o preloads issued behind it
         if (c0 > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PRE) : "memory");
         __syncthreads();
         if (c0 == 0) {
             // q as B fragments: lane (l15 = head, q4) of k-step ks holds dims 32 ks + 8 q4 .. + 8 of head l15
@@ -1196,22 +1198,31 @@ __global__ __launch_bounds__(256) void attn_oproj_mfma_kernel(AttnArgs a, unsign
     }
     __syncthreads();
     tls.phase(3);
-    float xf[8];
-    {
-        const float4 u = *reinterpret_cast<const float4*>(attn + lr * 8), v = *reinterpret_cast<const float4*>(attn + lr * 8 + 4);
-        xf[0] = u.x; xf[1] = u.y; xf[2] = u.z; xf[3] = u.w; xf[4] = v.x; xf[5] = v.y; xf[6] = v.z; xf[7] = v.w;
-    }
-    float* outp = a.opart + ((size_t)b * a.hkv + kvh) * a.H;
-    for (int p = 0; p < npass; ++p) {
-        const int row = r0 + p * RPP + rip;
-        uint4 w = (p < PRE) ? pre[p < PRE ? p : 0] : load_nt16(wbase + (size_t)row * ldw);
-        float wf[8];
-        WTraits<bf16>::decode(w, wf);
-        float acc = 0.f;
+    if constexpr (OPROJ) {
+        float xf[8];
+        {
+            const float4 u = *reinterpret_cast<const float4*>(attn + lr * 8), v = *reinterpret_cast<const float4*>(attn + lr * 8 + 4);
+            xf[0] = u.x; xf[1] = u.y; xf[2] = u.z; xf[3] = u.w; xf[4] = v.x; xf[5] = v.y; xf[6] = v.z; xf[7] = v.w;
+        }
+        float* outp = a.opart + ((size_t)b * a.hkv + kvh) * a.H;
+        for (int p = 0; p < npass; ++p) {
+            const int row = r0 + p * RPP + rip;
+            uint4 w = (p < PRE) ? pre[p < PRE ? p : 0] : load_nt16(wbase + (size_t)row * ldw);
+            float wf[8];
+            WTraits<bf16>::decode(w, wf);
+            float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc = fmaf(wf[j], xf[j], acc);
-        acc = group_sum<LPW>(acc);
-        if (lr == 0) outp[row] = acc;
+            for (int j = 0; j < 8; ++j) acc = fmaf(wf[j], xf[j], acc);
+            acc = group_sum<LPW>(acc);
+            if (lr == 0) outp[row] = acc;
+        }
+    } else {
+        const size_t ob = ((size_t)b * a.hq + (size_t)kvh * G) * D;
+        if (a.attn_direct16) {
+            for (int e = threadIdx.x; e < GD; e += 256) a.attn_direct16[ob + e] = from_f<bf16>(attn[e]);
+        } else {
+            for (int e = threadIdx.x; e < GD; e += 256) a.attn_direct[ob + e] = attn[e];
+        }
     }
     tls.phase(4);
     tls.end();
@@ -1567,6 +1578,7 @@ struct Engine {
     static constexpr int skip_attn = 0;
 #endif
     bool fused_attn = false;   // attn + o_proj in one kernel (short contexts, bf16 W_o)
+    bool attn_mfma_direct = false;   // the same kernel without the W_o slice as the whole-context batch attention while its workgroups (96 KB of LDS: one per CU) fit one round - batch x Hkv <= CUs; beyond (batch 64: 1.316 vs 1.258 ms) and with PGK_ATTN_MFMA_DIRECT=0: attn_decode_kernel
     bool attn_mfma = false;    // ... with Q.K^T and P.V on the matrix pipe from LDS-staged K/V (head_dim 128; PGK_ATTN_MFMA=0: the dot2 kernel)
     bool merged_oproj = false; // long contexts / fp8 W_o, one or two sequences: split-KV merge + o_proj in one kernel (PGK_MERGED_OPROJ=0: merge kernel + GEMV)
     int moproj_rows = 32;
@@ -1685,16 +1697,16 @@ static int gqa_chunks(int G) {
     return n;
 }
 
-template <int G>
+template <int G, bool OPROJ = true>
 static hipError_t launch_attn_mfma(dim3 grid, hipStream_t st, const AttnArgs& a) {
     constexpr int lds = 2 * AM_CHUNK * 256;
     static bool attr = false;
     if (!attr) {
-        const hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_oproj_mfma_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_oproj_mfma_kernel<G, OPROJ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (he != hipSuccess) return he;
         attr = true;
     }
-    return launch_k(attn_oproj_mfma_kernel<G>, grid, dim3(256), lds, st, a);
+    return launch_k(attn_oproj_mfma_kernel<G, OPROJ>, grid, dim3(256), lds, st, a);
 }
 
 template <int D>
@@ -1761,6 +1773,7 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
         if (fused && a.dep.sig_cnt) he = launch_k(attn_oproj_kernel<D, GG, true>, grid, dim3(256), 0, st, a);   \
         else if (fused && D == 128 && e->attn_mfma) he = launch_attn_mfma<GG>(grid, st, a);         \
         else if (fused) he = launch_k(attn_oproj_kernel<D, GG, false>, grid, dim3(256), 0, st, a);  \
+        else if (direct && D == 128 && e->attn_mfma_direct && m * (int)c.num_kv_heads <= e->cu_count) he = launch_attn_mfma<GG, false>(dim3(c.num_kv_heads, 1, m), st, a); \
         else if (direct) he = launch_k(attn_decode_kernel<D, GG, true>, grid, dim3(256), 0, st, a); \
         else he = launch_k(attn_decode_kernel<D, GG, false>, grid, dim3(256), 0, st, a);            \
         break;
@@ -2256,6 +2269,10 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         e->batched_min = (ev && atoi(ev) == 2) ? 3 : ((ev && atoi(ev) == 3) ? 9 : 5);   // 2: from 3 up; 3: the old threshold of 9
         const char* ed = getenv("PGK_ATTN_DIRECT");
         e->attn_direct_ok = c.max_seq_len <= 512 && !(ed && atoi(ed) == 0);
+        {
+            const char* amd = getenv("PGK_ATTN_MFMA_DIRECT");
+            e->attn_mfma_direct = e->attn_direct_ok && c.head_dim == 128 && !(amd && atoi(amd) == 0);
+        }
         // every projection's K must suit the MFMA decode kernels: K = 128 S with S in {8, 16, 24, 32} (activation
         // fragments in registers) or an LDS image of K x 16 bf16 that fits (K <= 4096); Llama-3-8B's down_proj
         // (K = 14336) does neither, so such models decode batches in GEMV chunks of 8 / 4 / 2 / 1

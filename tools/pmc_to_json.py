@@ -5,7 +5,7 @@ FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts half the
 (128-byte requests tallied as 64): reads are doubled, writes taken as they are (guide, section HBM)."""
 import collections, csv, glob, json, sys
 
-CLASS = [("attn_oproj_kernel", "attn"), ("finalize_kernel", "argmax"),
+CLASS = [("attn_oproj_", "attn"), ("finalize_kernel", "argmax"),
          ("fused_gemv_kernel<pgk::bf16, float, 1, 4, 0, 0,", "norm_qkv"), ("fused_gemv_kernel<pgk::bf16, float, 1, 2, 3, 2,", "gateup"),
          ("fused_gemv_kernel<pgk::bf16, float, 1, 1, 1, 1,", "down"), ("fused_gemv_kernel<pgk::bf16, float, 1, 4, 0, 3,", "lmhead")]
 

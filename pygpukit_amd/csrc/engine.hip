@@ -2094,14 +2094,14 @@ static pgk_status decode_chunk_packed(Engine* e, int b0, int M, bool last, hipSt
         }
         bf16* act16 = e->act16 + (size_t)b0 * I;
         if (carried) {
-            if (pgk_status r = pkgemm_resid_nt(attn16, QD, P.o, h, M, H, QD, (const bf16*)L.mlp_norm, x16, e->pk_ss, &ss_n, nullptr, 0, 0.f, st)) return r;
+            if (pgk_status r = pkgemm_resid_nt(attn16, QD, P.o, h, M, H, QD, (const bf16*)L.mlp_norm, x16, e->pk_ss, &ss_n, st)) return r;
             mark(KC_GATEUP);
             PkArgs gn{};
             gn.ss_in = e->pk_ss; gn.ss_n = ss_n; gn.ss_eps = c.norm_eps;
             if (pgk_status r = pkgemm_nt(x16, H, P.gate_up, act16, I, PK_EPI_SWIGLU, 1, M, 2 * I, H, &gn, st)) return r;
             mark(KC_DOWN);
             const bf16* gnext = l + 1 < c.num_layers ? (const bf16*)e->layers[l + 1].attn_norm : nullptr;
-            if (pgk_status r = pkgemm_resid_nt(act16, I, P.down, h, M, H, I, gnext, x16, e->pk_ss, &ss_n, nullptr, 0, 0.f, st)) return r;
+            if (pgk_status r = pkgemm_resid_nt(act16, I, P.down, h, M, H, I, gnext, x16, e->pk_ss, &ss_n, st)) return r;
             *launches += ((direct || e->merge_cnt) ? 5 : 6) + (l == 0 ? 1 : 0) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;
             continue;
         }
@@ -2567,12 +2567,12 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
         if (carried) {
             // o_proj adds the residual itself and leaves bf16(h * gamma_mlp) + row statistics; gate_up scales by 1 / rms;
             // down_proj does the same for the next layer's attention norm: 5 launches per layer
-            if (pgk_status r = pkgemm_resid_nt(attn, QD, e->packed[l].o, h32, n, H, QD, (const bf16*)L.mlp_norm, x, e->pk_ss, &ss_n, nullptr, 0, 0.f, st)) return r;
+            if (pgk_status r = pkgemm_resid_nt(attn, QD, e->packed[l].o, h32, n, H, QD, (const bf16*)L.mlp_norm, x, e->pk_ss, &ss_n, st)) return r;
             PkArgs gn{};
             gn.ss_in = e->pk_ss; gn.ss_n = ss_n; gn.ss_eps = c.norm_eps;
             if (pgk_status r = pkgemm_nt(x, H, e->packed[l].gate_up, act, I, PK_EPI_SWIGLU, 1, n, 2 * I, H, &gn, st)) return r;
             const bf16* gnext = l + 1 < c.num_layers ? (const bf16*)e->layers[l + 1].attn_norm : nullptr;
-            if (pgk_status r = pkgemm_resid_nt(act, I, e->packed[l].down, h32, n, H, I, gnext, x, e->pk_ss, &ss_n, nullptr, 0, 0.f, st)) return r;
+            if (pgk_status r = pkgemm_resid_nt(act, I, e->packed[l].down, h32, n, H, I, gnext, x, e->pk_ss, &ss_n, st)) return r;
             continue;
         }
         if (pk) { if (pgk_status r = pk_accum(attn, e->packed[l].o, QD, pk_so)) return r; }

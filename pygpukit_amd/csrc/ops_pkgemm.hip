@@ -375,9 +375,6 @@ struct PkResidArgs {
     const bf16* gamma_next;
     bf16* xpre;
     float* ss_out;
-    const float* ss_in;     // the rows in `a` may themselves be un-normalised... (not used by o_proj / down_proj: attention and
-    int ss_n;               // SwiGLU outputs are plain); kept for symmetry with PkArgs
-    float ss_eps;
 };
 
 template <int MB, int NTW>
@@ -517,10 +514,10 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_resid_kernel(PkResidArgs g)
 bool pkgemm_resid_ok(int N, int K) { return N % 32 == 0 && N / 16 <= PK_SS_LD && K % 512 == 0 && 16 * (K / 32) * 64 <= 128 * 1024; }
 
 pgk_status pkgemm_resid_nt(const bf16* a, int lda, const void* wp, float* h, int M, int N, int K, const bf16* gamma_next, bf16* xpre,
-                           float* ss_out, int* ss_n, const float* ss_in, int ss_in_n, float ss_eps, hipStream_t st) {
+                           float* ss_out, int* ss_n, hipStream_t st) {
     PGK_REQUIRE(M >= 1 && M <= 128 && pkgemm_resid_ok(N, K) && lda % 8 == 0, "pkgemm_resid: M=%d N=%d K=%d lda=%d not supported", M, N, K, lda);
     PGK_REQUIRE(!gamma_next || (xpre && ss_out && ss_n), "pkgemm_resid: the next norm's outputs are missing");
-    PkResidArgs g{a, lda, (const bf16*)wp, M, N, K, 0, 0, h, gamma_next, xpre, ss_out, ss_in, ss_in_n, ss_eps};
+    PkResidArgs g{a, lda, (const bf16*)wp, M, N, K, 0, 0, h, gamma_next, xpre, ss_out};
     // 16 rows x one n-tile while that still leaves at most one workgroup per CU (fewest bytes per workgroup); otherwise
     // 32 rows x one n-tile while the 32-row activation block fits the LDS budget, else 16 rows x two n-tiles
     const bool small = (N / 16) * ceil_div(M, 16) <= 256;

@@ -43,7 +43,7 @@ bool pkgemm_shape_ok(int N, int K, bool splittable);
 // gamma_next == nullptr: residual update only.  Returns the number of partial sums per row through *ss_n.
 bool pkgemm_resid_ok(int N, int K);
 pgk_status pkgemm_resid_nt(const bf16* a, int lda, const void* wp, float* h, int M, int N, int K, const bf16* gamma_next, bf16* xpre,
-                           float* ss_out, int* ss_n, const float* ss_in, int ss_in_n, float ss_eps, hipStream_t st);
+                           float* ss_out, int* ss_n, hipStream_t st);
 pgk_status pkgemm_nt(const bf16* a, int lda, const void* wp, void* c, int ldc, int epi, int splits, int M, int N, int K, const PkArgs* head,
                      hipStream_t st);
 

@@ -13,7 +13,7 @@ eng = S.build_engine_from_weights(cfg, w, max_seq_len=P + steps + 16, max_batch=
 pr = np.random.default_rng(1).integers(0, cfg["vocab_size"], (B, P))
 first = [int(np.argmax(eng.prefill([int(t) for t in pr[b]], seq=b))) for b in range(B)]
 eng.set_state(first, [P] * B)
-eager = len(sys.argv) > 5 and sys.argv[5] == "eager"   # un-captured steps: rocprofv3 (ROCm 7.2) crashes inside hipGraphLaunch on graphs that hold the packed-weight kernels
+eager = len(sys.argv) > 5 and sys.argv[5] == "eager"   # un-captured steps (per-launch timing without a graph; an earlier form of the packed-weight step crashed rocprofv3 inside hipGraphLaunch)
 if eager:
     def run(n):
         for _ in range(n):

@@ -74,8 +74,11 @@ __device__ unsigned long long g_pk_stamps[5][512][8];
 #define PK_STAMP(i) do { } while (0)
 #endif
 
-template <int NTW, int EPI>
+// MT = m-tiles per workgroup: 2 (32-row m-blocks) for prompts, 1 (16 rows) for M <= 64 - decode batches - where 32-row blocks
+// would leave half the CUs without a workgroup.
+template <int NTW, int EPI, int MT>
 __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
+    constexpr int PK_MT = MT, PK_MB = 16 * MT;
     extern __shared__ __attribute__((aligned(16))) char a_lds[];   // [PK_MB][ksteps * 32] bf16, chunk-swizzled rows
     __shared__ float ssred[4][PK_MB];
     PK_STAMP(0);
@@ -117,10 +120,11 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
         if (gm != nullptr && (is_q || is_k)) { gam[0] = to_f(gm[d]); gam[1] = to_f(gm[d + 64]); }
         if (is_q || is_k) {
             const uint32_t r0 = pk_lds_addr(reinterpret_cast<const char*>(rope_lds));
-            for (int j = wid; j < 16; j += 4) {                // instruction j: table j >> 3, rows 4 (j & 7) + q, 16 bytes per lane
-                const int row = 4 * (j & 7) + q;
+            constexpr int IPT = PK_MB / 4;                    // instructions per table: 4 rows each
+            for (int j = wid; j < 2 * IPT; j += 4) {           // instruction j: table j / IPT, rows 4 (j % IPT) + q, 16 bytes per lane
+                const int row = 4 * (j % IPT) + q;
                 const int pos = min(g.start_pos + min(m0 + row, g.M - 1), g.max_seq - 1);
-                pk_dma16(((j >> 3) ? g.rope_sin : g.rope_cos) + (size_t)pos * 64 + 4 * l15, r0 + j * 1024);
+                pk_dma16(((j / IPT) ? g.rope_sin : g.rope_cos) + (size_t)pos * 64 + 4 * l15, r0 + j * 1024);
             }
         }
     }
@@ -131,14 +135,14 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
     const bool scaled = g.ss_in != nullptr;
     if (scaled) {
         const int row = threadIdx.x >> 3, sub = threadIdx.x & 7;
-        const float* sp = g.ss_in + (size_t)min(m0 + row, g.M - 1) * PK_SS_LD + 8 * sub;   // a row's PK_SS_LD floats: 8 per thread, two 16-byte loads
+        const float* sp = g.ss_in + (size_t)min(m0 + min(row, PK_MB - 1), g.M - 1) * PK_SS_LD + 8 * sub;   // a row's PK_SS_LD floats: 8 per thread, two 16-byte loads
         const float4 u = *reinterpret_cast<const float4*>(sp), v = *reinterpret_cast<const float4*>(sp + 4);
         const float p8[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
         float ssum = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) ssum += (8 * sub + i < g.ss_n) ? p8[i] : 0.f;
         ssum = group8_sum(ssum);
-        if (sub == 0) inv_lds[row] = 1.0f / sqrtf(ssum / (float)g.K + g.ss_eps);
+        if (sub == 0 && row < PK_MB) inv_lds[row] = 1.0f / sqrtf(ssum / (float)g.K + g.ss_eps);
     }
     // activation block by LDS-DMA: instruction j fills LDS bytes [1024 j, +1024) = four 256-byte swizzle groups; lane i sits
     // in group 4 j + (i >> 4) at chunk position i & 15.  row = group / groups-per-row through a 16-bit reciprocal (exact for
@@ -547,7 +551,7 @@ pgk_status pkgemm_resid_nt(const bf16* a, int lda, const void* wp, float* h, int
 // K splits for the N = hidden projections: enough workgroups to cover the chip, and a K range per workgroup whose
 // activation block (32 rows) fits the LDS budget.  0: no split count works for this K.
 int pkgemm_pick_splits(int M, int N, int K) {
-    const int nblk = N / 64, mblk = ceil_div(M, PK_MB);
+    const int nblk = N / 64, mblk = ceil_div(M, M <= 64 ? 16 : 32);
     int best = 0;
     for (int s = 1; s <= 16; ++s) {
         if (K % (s * 128) != 0 || K / s > 2048) continue;
@@ -572,7 +576,8 @@ pgk_status pkgemm_nt(const bf16* a, int lda, const void* wp, void* c, int ldc, i
     g.a = a; g.lda = lda; g.wp = (const bf16*)wp; g.M = M; g.N = N; g.K = K; g.c = c; g.ldc = ldc;
     g.ksteps = K / splits / 32;
     g.splits = splits;
-    g.mblk = ceil_div(M, PK_MB);
+    const int mt = M <= 64 ? 1 : 2;                  // 16-row m-blocks for decode batches: twice the workgroups, fewer bytes each
+    g.mblk = ceil_div(M, 16 * mt);
     g.tiles_per_cb = 4;
     g.tile_b_off = 0;
     if (epi == PK_EPI_SWIGLU) {
@@ -587,19 +592,21 @@ pgk_status pkgemm_nt(const bf16* a, int lda, const void* wp, void* c, int ldc, i
     } else {
         g.nblk = N / 64;
     }
-    const size_t lds = (size_t)PK_MB * g.ksteps * 64;
+    const size_t lds = (size_t)16 * mt * g.ksteps * 64;
     PGK_REQUIRE(lds <= 128 * 1024, "pkgemm: K per workgroup %d too long for the LDS activation block", g.ksteps * 32);
     const int grid = ceil_div(g.nblk, 8) * 8 * g.mblk * splits;     // whole groups of 8 n-blocks (see the id mapping in the kernel)
-#define PGK_PK_LAUNCH(NTWV, EPIV)                                                                                  \
+#define PGK_PK_LAUNCH2(NTWV, EPIV, MTV)                                                                            \
     {                                                                                                              \
         static size_t attr = 0;                                                                                    \
         if (lds > 48 * 1024 && lds > attr) {                                                                       \
-            PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pkgemm_kernel<NTWV, EPIV>),            \
+            PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pkgemm_kernel<NTWV, EPIV, MTV>),       \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));     \
             attr = 128 * 1024;                                                                                     \
         }                                                                                                          \
-        pkgemm_kernel<NTWV, EPIV><<<grid, PK_THREADS, lds, st>>>(g);                                               \
+        pkgemm_kernel<NTWV, EPIV, MTV><<<grid, PK_THREADS, lds, st>>>(g);                                          \
     }
+#define PGK_PK_LAUNCH(NTWV, EPIV)                                                                                  \
+    if (mt == 1) PGK_PK_LAUNCH2(NTWV, EPIV, 1) else PGK_PK_LAUNCH2(NTWV, EPIV, 2)
     switch (epi) {
         case PK_EPI_BF16: PGK_PK_LAUNCH(1, PK_EPI_BF16) break;
         case PK_EPI_SLAB: PGK_PK_LAUNCH(1, PK_EPI_SLAB) break;
@@ -608,6 +615,7 @@ pgk_status pkgemm_nt(const bf16* a, int lda, const void* wp, void* c, int ldc, i
         case PK_EPI_QKV: PGK_PK_LAUNCH(2, PK_EPI_QKV) break;
         default: return set_error(PGK_ERR_INVALID, "pkgemm: unknown epilogue %d", epi);
     }
+#undef PGK_PK_LAUNCH2
 #undef PGK_PK_LAUNCH
     PGK_CHECK_HIP(hipGetLastError());
     return PGK_OK;

@@ -576,10 +576,7 @@ pgk_status pkgemm_nt(const bf16* a, int lda, const void* wp, void* c, int ldc, i
     g.a = a; g.lda = lda; g.wp = (const bf16*)wp; g.M = M; g.N = N; g.K = K; g.c = c; g.ldc = ldc;
     g.ksteps = K / splits / 32;
     g.splits = splits;
-    // 16-row m-blocks up to 96 rows (decode batches, short prompts): twice the workgroups, fewer bytes each (measured: 96 rows
-    // 1.178 vs 1.224 ms per prefill, 128 rows 1.270 vs 1.243 - there the 32-row blocks re-read the weights half as often)
-    const int mt = M <= 96 ? 1 : 2;
-    g.mblk = ceil_div(M, 16 * mt);
+    // (m-tile count chosen below, once the n-block count of the epilogue is known)
     g.tiles_per_cb = 4;
     g.tile_b_off = 0;
     if (epi == PK_EPI_SWIGLU) {
@@ -594,6 +591,13 @@ pgk_status pkgemm_nt(const bf16* a, int lda, const void* wp, void* c, int ldc, i
     } else {
         g.nblk = N / 64;
     }
+    // 16-row m-blocks (twice the workgroups, fewer bytes each) while they still fit one round at one workgroup per CU, and
+    // always up to 96 rows; else 32-row blocks, which re-read the weights half as often (measured at 128 rows: QKV 256 x 16-row
+    // workgroups instead of 128 x 32-row ones pays, gate_up with 384 does not)
+    static const int mt_force = [] { const char* e = getenv("PGK_PK_MT"); return e ? atoi(e) : 0; }();
+    int mt = (M <= 96 || g.nblk * splits * ceil_div(M, 16) <= 256) ? 1 : 2;
+    if (mt_force == 1 || mt_force == 2) mt = mt_force;
+    g.mblk = ceil_div(M, 16 * mt);
     const size_t lds = (size_t)16 * mt * g.ksteps * 64;
     PGK_REQUIRE(lds <= 128 * 1024, "pkgemm: K per workgroup %d too long for the LDS activation block", g.ksteps * 32);
     const int grid = ceil_div(g.nblk, 8) * 8 * g.mblk * splits;     // whole groups of 8 n-blocks (see the id mapping in the kernel)

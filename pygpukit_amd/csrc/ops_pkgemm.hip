@@ -109,15 +109,18 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
     // the gammas are requested first of all (first in = first out).  (Per-lane loads of the 16 entries a lane needs were
     // 64 more wave-instructions through the CU's texture addresser, which is what bounds this kernel's first 2.8 us.)
     __shared__ __attribute__((aligned(16))) float rope_lds[EPI == PK_EPI_QKV ? 2 * PK_MB * 64 : 4];
-    float gam[2];
-    bool is_q = false, is_k = false;
+    uint16_t gbits[2] = {0, 0};
+    bool is_q = false, is_k = false, has_gamma = false;
     if constexpr (EPI == PK_EPI_QKV) {
         is_q = cb < g.hq;
         is_k = !is_q && cb < g.hq + g.hkv;
         const int d = 16 * wid + l15;                          // < 64; the wave's second tile holds d + 64
+        // unconditional loads from an always-valid address, converted where they are used: under a branch the compiler
+        // finishes the conversion before the join, i.e. waits for the loads right here, ahead of every DMA of the kernel
         const bf16* gm = is_q ? g.q_gamma : g.k_gamma;
-        gam[0] = gam[1] = 1.f;
-        if (gm != nullptr && (is_q || is_k)) { gam[0] = to_f(gm[d]); gam[1] = to_f(gm[d + 64]); }
+        has_gamma = gm != nullptr && (is_q || is_k);
+        const bf16* gsafe = has_gamma ? gm : reinterpret_cast<const bf16*>(g.rope_cos);
+        gbits[0] = gsafe[d].bits; gbits[1] = gsafe[d + 64].bits;
         if (is_q || is_k) {
             const uint32_t r0 = pk_lds_addr(reinterpret_cast<const char*>(rope_lds));
             constexpr int IPT = PK_MB / 4;                    // instructions per table: 4 rows each
@@ -133,16 +136,16 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
     // 8 threads per row; visible to everyone after the barrier that follows the DMA wait
     __shared__ float inv_lds[PK_MB];
     const bool scaled = g.ss_in != nullptr;
-    if (scaled) {
+    // The row statistics are requested here and reduced only after this wave's DMAs and weight ring are issued (reducing on
+    // the spot held those back by an L2 round trip).  Unconditional load, valid dummy address when there is nothing to scale:
+    // under a branch the compiler completes the loaded values before the join - the same wait.
+    float4 ssu, ssv;
+    {
         const int row = threadIdx.x >> 3, sub = threadIdx.x & 7;
-        const float* sp = g.ss_in + (size_t)min(m0 + min(row, PK_MB - 1), g.M - 1) * PK_SS_LD + 8 * sub;   // a row's PK_SS_LD floats: 8 per thread, two 16-byte loads
-        const float4 u = *reinterpret_cast<const float4*>(sp), v = *reinterpret_cast<const float4*>(sp + 4);
-        const float p8[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-        float ssum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ssum += (8 * sub + i < g.ss_n) ? p8[i] : 0.f;
-        ssum = group8_sum(ssum);
-        if (sub == 0 && row < PK_MB) inv_lds[row] = 1.0f / sqrtf(ssum / (float)g.K + g.ss_eps);
+        const float* sp = scaled ? g.ss_in + (size_t)min(m0 + min(row, PK_MB - 1), g.M - 1) * PK_SS_LD + 8 * sub   // a row's PK_SS_LD floats: 8 per thread
+                                 : reinterpret_cast<const float*>(g.wp) + 8 * sub;
+        ssu = *reinterpret_cast<const float4*>(sp);
+        ssv = *reinterpret_cast<const float4*>(sp + 4);
     }
     // activation block by LDS-DMA: instruction j fills LDS bytes [1024 j, +1024) = four 256-byte swizzle groups; lane i sits
     // in group 4 j + (i >> 4) at chunk position i & 15.  row = group / groups-per-row through a 16-bit reciprocal (exact for
@@ -165,6 +168,15 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
     for (int s = 0; s < PK_RING; ++s)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) wr[t][s] = *reinterpret_cast<const uint4*>(wrun[t] + (size_t)min(s, KS - 1) * 512);   // default cache policy: the other m-blocks re-read these bytes from L2
+    if (scaled) {
+        const int row = threadIdx.x >> 3, sub = threadIdx.x & 7;
+        const float p8[8] = {ssu.x, ssu.y, ssu.z, ssu.w, ssv.x, ssv.y, ssv.z, ssv.w};
+        float ssum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ssum += (8 * sub + i < g.ss_n) ? p8[i] : 0.f;
+        ssum = group8_sum(ssum);
+        if (sub == 0 && row < PK_MB) inv_lds[row] = 1.0f / sqrtf(ssum / (float)g.K + g.ss_eps);
+    }
     PK_STAMP(1);
     if constexpr (NTW == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // in-order return: every DMA has landed
     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -316,8 +328,8 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_kernel(PkArgs g) {
                         const int mi = mt * 16 + 4 * q + r;
                         const float ss = (ssred[0][mi] + ssred[1][mi]) + (ssred[2][mi] + ssred[3][mi]);
                         const float inv = 1.0f / sqrtf(ss / 128.f + g.eps);
-                        x0[mt][r] = x0[mt][r] * inv * gam[0];
-                        x1[mt][r] = x1[mt][r] * inv * gam[1];
+                        x0[mt][r] = x0[mt][r] * inv * bf16_bits_to_f(gbits[0]);
+                        x1[mt][r] = x1[mt][r] * inv * bf16_bits_to_f(gbits[1]);
                     }
             }
 #pragma unroll
@@ -410,9 +422,14 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_resid_kernel(PkResidArgs g)
         em[i] = e / NC; en[i] = e % NC;
         hold[i] = g.h[(size_t)min(m0 + em[i], g.M - 1) * g.N + n0 + en[i]];
     }
-    float gnx[EPT];
+    // (unconditional loads, converted where they are used: under a branch the compiler waits for them right here - two
+    // serialised L2 round trips in front of every DMA of the kernel in the first version)
+    uint16_t gnb[EPT];
+    {
+        const bf16* gsafe = g.gamma_next ? g.gamma_next + n0 : g.a;
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) gnx[i] = g.gamma_next ? to_f(g.gamma_next[n0 + en[i]]) : 0.f;
+        for (int i = 0; i < EPT; ++i) gnb[i] = gsafe[en[i]].bits;
+    }
     {
         const uint32_t lds0 = pk_lds_addr(a_lds);
         const int ndma = MB * rb / 1024, gpr = KS >> 2;
@@ -508,7 +525,7 @@ __global__ __launch_bounds__(PK_THREADS) void pkgemm_resid_kernel(PkResidArgs g)
         const bool ok = m0 + m < g.M;
         if (ok) g.h[(size_t)(m0 + m) * g.N + n0 + n] = v;
         if (g.gamma_next) {
-            if (ok) g.xpre[(size_t)(m0 + m) * g.N + n0 + n] = from_f<bf16>(v * gnx[i]);
+            if (ok) g.xpre[(size_t)(m0 + m) * g.N + n0 + n] = from_f<bf16>(v * bf16_bits_to_f(gnb[i]));
             const float sq = group_sum<NC>(v * v);                 // the NC threads of a row are consecutive lanes
             if (n == 0 && ok) g.ss_out[(size_t)(m0 + m) * PK_SS_LD + cb] = sq;
         }

@@ -22,6 +22,9 @@ for epi, nm in names.items():
     st = buf[epi].astype(np.int64)
     live = st[:, 0] > 0
     st = st[live]
+    if not live.any():
+        print(f"{nm}: not launched (the N = hidden projections carry the norm: pkgemm_resid_kernel)")
+        continue
     t0 = st[:, 0].min()
     print(f"{nm}: {live.sum()} workgroups; start spread {(st[:, 0].max() - t0) / 100:.2f} us")
     for i, lab in enumerate(["start", "loads issued", "A landed + barrier", "first 16 k-steps", "k loop done", "end"]):

@@ -35,6 +35,8 @@ namespace pgk {
 pgk_status engine_gemm_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, void* C, bool accum_f32, int M,
                           int N, int K, hipStream_t st);
 int wsgemm_pick_splits(int N, int K, bool allow_split);
+int engine_gemm_pick_splits(int M, int N, int K);
+pgk_status engine_gemm_nt_slabs(const bf16* A, const void* W, float* slabs, int splits, int M, int N, int K, hipStream_t st);
 pgk_status gemm_fp8_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, void* c, bool accum_f32, int M,
                        int N, int K, hipStream_t st);
 pgk_status quantize_fp8_rows_bf16(const bf16* x, uint8_t* out, float* scale, int M, int K, hipStream_t st);
@@ -2441,12 +2443,18 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     const bool pk = ws && e->packed_ok;
     const int pk_so = pk ? pkgemm_pick_splits(n, H, QD) : 1, pk_sd = pk ? pkgemm_pick_splits(n, H, I) : 1;
     const bool pk_heads = pk && D == 128;       // QKV epilogue: per-head norm + RoPE + cache write inside the projection
+    // long prompts, bf16 weights: the N = hidden projections as split-K slabs when their 128-tiles do not cover the chip
+    // (QKV / gate_up were tried too - their consumers can sum slabs - and measured slightly slower: 3.06 vs 2.99 ms at S = 512)
+    const bool gsplit = !ws && c.weight_format == 0;
+    const int g_so = gsplit ? engine_gemm_pick_splits(n, H, QD) : 1, g_sd = gsplit ? engine_gemm_pick_splits(n, H, I) : 1;
+    const bool use_slabs = ws || g_so > 1 || g_sd > 1;
     size_t slab_elems = (size_t)(s_o > s_d ? s_o : s_d) * n * H;
+    if ((size_t)(g_so > g_sd ? g_so : g_sd) * n * H > slab_elems) slab_elems = (size_t)(g_so > g_sd ? g_so : g_sd) * n * H;
     if (pk && (size_t)(pk_so > pk_sd ? pk_so : pk_sd) * n * H > slab_elems) slab_elems = (size_t)(pk_so > pk_sd ? pk_so : pk_sd) * n * H;
     if (s_qkv > 1 && (size_t)s_qkv * n * NQKV > slab_elems) slab_elems = (size_t)s_qkv * n * NQKV;
     if (s_gu > 1 && (size_t)s_gu * n * 2 * I > slab_elems) slab_elems = (size_t)s_gu * n * 2 * I;
     const size_t need = (size_t)n * H * 4 + ((size_t)n * H + (size_t)n * NQKV + (size_t)n * QD + (size_t)n * 2 * I + (size_t)n * I) * 2 +
-                        (ws ? slab_elems * 4 : 0) + 512 + (c.weight_format == 2 ? (size_t)n * maxk + (size_t)n * (maxk / 128) * 4 + 512 : 0);
+                        (use_slabs ? slab_elems * 4 : 0) + 512 + (c.weight_format == 2 ? (size_t)n * maxk + (size_t)n * (maxk / 128) * 4 + 512 : 0);
     if (need > e->pf_bytes) {
         if (e->pf) PGK_CHECK_HIP(hipStreamSynchronize(st));
         if (e->pf) pgk_free(e->pf);
@@ -2473,7 +2481,7 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     bf16* gu = (bf16*)p; p += (size_t)n * 2 * I * 2;
     bf16* act = (bf16*)p; p += (size_t)n * I * 2;
     float* slabs = (float*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-    uint8_t* q8 = (uint8_t*)(((uintptr_t)slabs + (ws ? slab_elems * 4 : 0) + 255) & ~(uintptr_t)255);   // fp8 activations [n][maxk]
+    uint8_t* q8 = (uint8_t*)(((uintptr_t)slabs + (use_slabs ? slab_elems * 4 : 0) + 255) & ~(uintptr_t)255);   // fp8 activations [n][maxk]
     float* q8s = (float*)(q8 + (size_t)n * maxk);                                                          // their scales [n][maxk/128]
     int pending = 0;   // split-K slabs of the previous projection still to be added into h32 by the next norm
     // fp8act: RMSNorm and SwiGLU leave their result in q8/q8s themselves (x_in == nullptr); attention output is
@@ -2487,7 +2495,11 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
                 if (pgk_status r = quantize_fp8_rows_bf16(x_in, q8, q8s, n, K_, st)) return r;
             return gemm_fp8_nt(q8, q8s, (const uint8_t*)w, (const bf16*)sc, h32, true, n, N_, K_, st);
         }
-        if (!ws) return engine_gemm_nt(x_in, w, (const bf16*)sc, fp8, h32, true, n, N_, K_, st);
+        if (!ws) {
+            const int gs = gsplit ? engine_gemm_pick_splits(n, N_, K_) : 1;
+            if (gs > 1) { pending = gs; return engine_gemm_nt_slabs(x_in, w, slabs, gs, n, N_, K_, st); }
+            return engine_gemm_nt(x_in, w, (const bf16*)sc, fp8, h32, true, n, N_, K_, st);
+        }
         if (splits == 1) return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, h32, nullptr, 2, 1, n, N_, K_, st);
         pending = splits;
         return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, slabs, nullptr, 1, splits, n, N_, K_, st);

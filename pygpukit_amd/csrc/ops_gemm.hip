@@ -188,8 +188,10 @@ struct TileRegsFp8KN {
 };
 
 template <class T, int BM, int BN, int MODE, int EPI>
+// kps > 0 (B_NT only, EPI 2): split-K - workgroup z multiplies k in [z * kps, (z + 1) * kps) and stores its fp32 partial tile into
+// slab z of Cv ([splits][M][N]); the consumer sums the slabs (the engine's RMSNorm kernel does, as for the skinny GEMMs).
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(const T* A, const void* Bv, const bf16* bscale,
-                                                                const T* bias, void* Cv, int M, int N, int K) {
+                                                                const T* bias, void* Cv, int M, int N, int K, int kps) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -206,9 +208,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(const T* A, con
     TileRegsFp8NT<BN> rb_f8nt;
     TileRegsFp8KN<BN> rb_f8kn;
 
+    const int kbeg = kps > 0 ? (int)blockIdx.z * kps : 0, kend = kps > 0 ? min(K, kbeg + kps) : K;
     auto load_tiles = [&](int k0) {
-        ra.load(A, m0, M, k0, K, K);
-        if constexpr (MODE == B_NT) rb_nt.load((const T*)Bv, n0, N, k0, K, K);
+        ra.load(A, m0, M, k0, kend, K);
+        if constexpr (MODE == B_NT) rb_nt.load((const T*)Bv, n0, N, k0, kend, K);
         else if constexpr (MODE == B_NN) rb_nn.load((const T*)Bv, n0, N, k0, K);
         else if constexpr (MODE == B_NT_FP8) rb_f8nt.load((const uint8_t*)Bv, bscale, n0, N, k0, K);
         else rb_f8kn.load((const uint8_t*)Bv, bscale, n0, N, k0, K);
@@ -227,13 +230,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(const T* A, con
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (K + GEMM_BK - 1) / GEMM_BK;
-    load_tiles(0);
+    const int nk = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
+    load_tiles(kbeg);
     store_tiles(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * GEMM_BK);
+        if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * GEMM_BK);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint4 fa[TM], fb[TN];
@@ -266,6 +269,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(const T* A, con
                 const int row = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
                 if (row >= M) continue;
                 if constexpr (EPI == 0) reinterpret_cast<T*>(Cv)[(size_t)row * N + col] = from_f<T>(acc[i][j][r] + b);
+                else if constexpr (EPI == 2) reinterpret_cast<float*>(Cv)[((size_t)blockIdx.z * M + row) * N + col] = acc[i][j][r];   // split-K slab
                 else reinterpret_cast<float*>(Cv)[(size_t)row * N + col] += acc[i][j][r] + b;  // fp32 residual stream
             }
         }
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256) void gemm_simple_kernel(const T* A, const T* B
 
 template <class T, int BM, int BN, int MODE, int EPI>
 static pgk_status launch_mfma(const T* A, const void* B, const bf16* bscale, const T* bias, void* C, int M, int N, int K,
-                              hipStream_t st) {
+                              hipStream_t st, int splits = 1) {
     constexpr size_t LDS = 2 * (size_t)(BM + BN) * 128;
     static bool attr_done = false;
     if (LDS > 48 * 1024 && !attr_done) {
@@ -325,8 +329,9 @@ static pgk_status launch_mfma(const T* A, const void* B, const bf16* bscale, con
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_done = true;
     }
-    dim3 grid(ceil_div(N, BN), ceil_div(M, BM));
-    gemm_mfma_kernel<T, BM, BN, MODE, EPI><<<grid, GEMM_THREADS, LDS, st>>>(A, B, bscale, bias, C, M, N, K);
+    dim3 grid(ceil_div(N, BN), ceil_div(M, BM), splits);
+    const int kps = splits > 1 ? ceil_div(ceil_div(K, splits), GEMM_BK) * GEMM_BK : 0;
+    gemm_mfma_kernel<T, BM, BN, MODE, EPI><<<grid, GEMM_THREADS, LDS, st>>>(A, B, bscale, bias, C, M, N, K, kps);
     PGK_CHECK_HIP(hipGetLastError());
     return PGK_OK;
 }
@@ -374,6 +379,23 @@ __global__ __launch_bounds__(256) void dequant_fp8_blocks_kernel(const uint8_t* 
         o[0] = lo;
         o[1] = hi;
     }
+}
+
+// internal (engine prefill): N = hidden projections of a long prompt whose 128 x 128 tiles do not cover the chip (M = 2048,
+// N = 1024: 128 tiles; the 64 x 64 tiles that do cover it run at 200-290 TFLOP/s) - the 128-tile kernel split along K into
+// `splits` fp32 slabs [splits][M][N] that the next RMSNorm sums.  Returns the number of slabs through the argument; 1 = not used.
+int engine_gemm_pick_splits(int M, int N, int K) {
+    static const bool off = [] { const char* e = getenv("PGK_GEMM_SPLITK"); return e && atoi(e) == 0; }();   // A/B switch
+    const long long tiles = (long long)ceil_div(M, 128) * ceil_div(N, 128);
+    if (off || M <= 128 || tiles >= 192 || use_gemm256(M, N, K)) return 1;
+    int s = (int)(256 / tiles);
+    if (s > 4) s = 4;
+    while (s > 1 && K / s < 512) --s;
+    return s < 1 ? 1 : s;
+}
+pgk_status engine_gemm_nt_slabs(const bf16* A, const void* W, float* slabs, int splits, int M, int N, int K, hipStream_t st) {
+    PGK_REQUIRE(splits >= 2 && K % 8 == 0, "engine_gemm_nt_slabs: splits=%d K=%d", splits, K);
+    return launch_mfma<bf16, 128, 128, B_NT, 2>(A, W, nullptr, nullptr, slabs, M, N, K, st, splits);
 }
 
 // internal (engine prefill): bf16 A against a bf16 or fp8 (+128x128 bf16 block scales) weight W[N,K];

@@ -403,7 +403,12 @@ pgk_status pgk_engine_profile_step(pgk_engine e, int batch, int n_iters, float* 
  * (times in 10 ns ticks from the step's first start).  `warm` replays precede the measured one; the state advances by
  * warm + 1 steps; the engine's own captured graph is untouched. */
 pgk_status pgk_engine_timeline(pgk_engine e, int batch, int warm, uint64_t* h_out, int max_launches, int* n_launches, pgk_stream s);
-/* Capture decode_step(batch) into a hipGraph owned by the engine / replay it. */
+/* Capture decode_step(batch) into hipGraphs owned by the engine / replay them.  A step has two launch sequences - the
+ * short-context one (contexts <= 512: whole-context attention kernels, 4L+2 launches at batch 1) and the split-KV one
+ * (5L+2) - both correct at ANY context; capture records both when the cache can hold more than 512 rows, and replay
+ * picks per step by the CONTEXT the step will see, from the positions last given to pgk_engine_set_state plus the steps
+ * enqueued since (a host-side bound, a speed hint only).  The reference's fixed cache takes any max_seq_len with one code
+ * path (src/pygpukit/llm/layers/attention.py:128-146, llm/decode/m1_graph.py:248-325). */
 pgk_status pgk_engine_capture(pgk_engine e, int batch, pgk_stream s);
 pgk_status pgk_engine_replay(pgk_engine e, int n_steps, pgk_stream s);
 /* Read back: logits of the last step (device pointer, fp32 [batch,V]), token log (host copy). */
@@ -423,9 +428,6 @@ pgk_status pgk_engine_set_sampling(pgk_engine e, float temperature, int top_k, f
  * step's last kernel: the in-kernel shader clock between two steps is d(memtime)/d(memrealtime) x 100 MHz
  * (MI355X_MICROARCH.md, DVFS give-back item 6).  h_out: uint64[2 * n_steps]. */
 pgk_status pgk_engine_read_clock(pgk_engine e, uint64_t* h_out, int n_steps, pgk_stream s);
-/* Diagnostic for the dual-chain step (consecutive layer kernels on two graph branches, hand-offs through device
- * counters): h_out[0] = steps completed, [1] = non-zero if a wait ever timed out, [2 + k] = arrivals of layer kernel k. */
-pgk_status pgk_engine_dep_state(pgk_engine e, uint32_t* h_out, int n);
 /* KV cache access for parity tests: pointers to layer `l`'s K and V caches [max_batch,Hkv,max_seq,D] bf16 */
 pgk_status pgk_engine_kv_ptr(pgk_engine e, int layer, void** k, void** v);
 /* device int32[max_batch] arrays holding each sequence's current token and position (the step's inputs and,

@@ -108,7 +108,6 @@ _PROTOS = {
     "pgk_engine_read_tokens": [_V, c_i32_p, _I, _I, _V], "pgk_engine_reset_log": [_V, _V],
     "pgk_engine_set_sampling": [_V, _F, _I, _F, C.POINTER(_F), _I, _V],
     "pgk_engine_read_clock": [_V, C.POINTER(C.c_uint64), _I, _V],
-    "pgk_engine_dep_state": [_V, C.POINTER(C.c_uint32), _I],
     "pgk_engine_kv_ptr": [_V, _I, c_void_pp, c_void_pp], "pgk_engine_state_ptr": [_V, c_void_pp, c_void_pp], "pgk_engine_launches_per_step": [_V, C.POINTER(_I)],
     "pgk_comm_unique_id": [C.c_char_p], "pgk_comm_init": [c_void_pp, C.c_char_p, _I, _I], "pgk_comm_destroy": [_V],
     "pgk_comm_broadcast": [_V, _V, _Z, _I, _V], "pgk_comm_all_gather": [_V, _V, _V, _Z, _V],

@@ -56,10 +56,16 @@ template <> __device__ __forceinline__ void store_x<bf16>(bf16* xs, int i, float
 // (A load under a per-lane guard, or accumulated inside a conditional, is waited for on the spot by
 // hipcc: that serialised dozens of memory round trips per kernel in the first version.)  C == 0 is the
 // generic any-K path.
-// DUAL: the instance wired into a dual chain (engine_common.cuh): waits for its predecessor after the weight preload, reads
-// and writes activations with sc1 accesses, signals at the end.  A separate instance, so the ordinary step pays nothing.
-template <class WT, class XT, int M, int R, int PRO, int EPI, int C, bool DUAL = false>
-__global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned long long* tl) {
+template <class WT, class XT, int M, int R, int PRO, int EPI, int C>
+__global__ __launch_bounds__(256) void fused_gemv_kernel(unsigned long long* tl, const void* w_, const bf16* wscale_, const float* x_, const bf16* gamma_,
+                                                         const float* aux_, int N_, int naux_, FusedArgs a) {
+    // The first 14 dwords of the kernel arguments - everything the load-issue phase needs - arrive PRELOADED in SGPRs
+    // (-mllvm -amdgpu-kernarg-preload-count=14, see the Makefile): x_ = the fp32 input rows (FusedArgs::h for the norm
+    // prologues, FusedArgs::xin for PRO_PLAIN), aux_ / naux_ = the o_proj partial vectors and their count (PRO_NORM_SUM) or the residual rows and
+    // their leading dimension (EPI_RESID).  What is left in the by-value struct (eps, out, ld_out, h_out, argmax slots) is
+    // fetched by scalar loads that complete under the weight stream.  Before, every load of the kernel waited for the
+    // struct's s_load through a scalar cache the dispatch had just invalidated.
+    static_assert(!(PRO == PRO_NORM_SUM && EPI == EPI_RESID), "aux_ cannot carry partial vectors and residual rows at once");
     const TLStamp tls(tl);
     constexpr int NW = WTraits<WT>::NW;
     constexpr bool FP8 = std::is_same<WT, fp8e4m3>::value;
@@ -71,8 +77,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
     __shared__ float s_bv[4][M];
     __shared__ int s_bi[4][M];
     const int K = (C > 0) ? KC : a.K;
-    const int N = a.N;
-    constexpr bool coh = DUAL;
+    const int N = N_;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     constexpr int OUT_PER_TRIP = (EPI == EPI_SWIGLU) ? R / 2 : R;
     const int wave = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
@@ -91,43 +96,39 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
         // the weight rows come from HBM: issued first, the activations are usable ~1 us before the weights land and the
         // whole prologue (norm statistic, barrier, LDS image) runs under the weight latency.  (The first version issued
         // the weights first: the prologue then started only after the last weight chunk had arrived - in-kernel stamps,
-        // tools/phase_stamps.py.)  In a dual chain the activations do not exist yet: weights, then the wait, then them.
+        // tools/phase_stamps.py.)
         const int nf = min(wave * OUT_PER_TRIP, N - 1);  // waves beyond N recompute the last rows (never stored)
         auto load_weights = [&]() {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int row = row_of(nf, r);
-                const WT* wr = reinterpret_cast<const WT*>(a.w) + (size_t)row * KC;
+                const WT* wr = reinterpret_cast<const WT*>(w_) + (size_t)row * KC;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const int k0 = lane * NW + c * 64 * NW;
                     pre[r][c] = load_nt16(wr + k0);
-                    if constexpr (FP8) psc[r][c] = to_f(a.wscale[(size_t)(row >> 7) * (KC >> 7) + (k0 >> 7)]);
+                    if constexpr (FP8) psc[r][c] = to_f(wscale_[(size_t)(row >> 7) * (KC >> 7) + (k0 >> 7)]);
                 }
             }
         };
-        if constexpr (DUAL) {
-            load_weights();
-            dep_wait(a.dep);       // every load of bytes another kernel of this step wrote is an sc1 load from here on
-        }
         constexpr bool NORM = PRO == PRO_NORM || PRO == PRO_NORM_SUM;
         constexpr int NP = (PRO == PRO_NORM_SUM) ? 8 : 1;
-        const int np = (PRO == PRO_NORM_SUM) ? a.nsplit : 1;
+        const int np = (PRO == PRO_NORM_SUM) ? naux_ : 1;
         float hv[M][KJ], gv[NORM ? KJ : 1], pvs[PRO == PRO_NORM_SUM ? M : 1][PRO == PRO_NORM_SUM ? KJ : 1][NP];
         // ---- activation loads ----
         if constexpr (EPI == EPI_RESID) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int m = 0; m < M; ++m) resv[r][m] = ld_act(a.res + (size_t)m * a.ld_out + min(nf + r, N - 1), coh);
+                for (int m = 0; m < M; ++m) resv[r][m] = *(aux_ + (size_t)m * naux_ + min(nf + r, N - 1));
         }
         if constexpr (NORM) {
 #pragma unroll
             for (int j = 0; j < KJ; ++j) {
                 const int i = threadIdx.x + 256 * j;
-                gv[j] = to_f(a.gamma[i]);
+                gv[j] = to_f(gamma_[i]);
 #pragma unroll
-                for (int m = 0; m < M; ++m) hv[m][j] = ld_act(a.h + (size_t)m * KC + i, coh);
+                for (int m = 0; m < M; ++m) hv[m][j] = *(x_ + (size_t)m * KC + i);
             }
             if constexpr (PRO == PRO_NORM_SUM) {
                 // partial vectors: unconditional clamped loads, masked adds below (one round trip for up to 8)
@@ -137,19 +138,17 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
                     for (int j = 0; j < KJ; ++j)
 #pragma unroll
                         for (int p = 0; p < NP; ++p)
-                            pvs[m][j][p] = ld_act(a.part + ((size_t)m * np + min(p, np - 1)) * KC + threadIdx.x + 256 * j, coh);
+                            pvs[m][j][p] = *(aux_ + ((size_t)m * np + min(p, np - 1)) * KC + threadIdx.x + 256 * j);
             }
         } else if constexpr (PRO == PRO_PLAIN) {
 #pragma unroll
             for (int m = 0; m < M; ++m)
 #pragma unroll
-                for (int j = 0; j < KJ; ++j) hv[m][j] = ld_act(a.xin + (size_t)m * KC + threadIdx.x + 256 * j, coh);
+                for (int j = 0; j < KJ; ++j) hv[m][j] = *(x_ + (size_t)m * KC + threadIdx.x + 256 * j);
         }
-        if constexpr (!DUAL) {
-            __builtin_amdgcn_sched_barrier(0);      // keep the compiler from hoisting the weight stream above the small loads
-            load_weights();
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the compiler from hoisting the weight stream above the small loads
+        load_weights();
+        __builtin_amdgcn_sched_barrier(0);
         // ---- prologue ALU, exact trip counts ----
         if constexpr (NORM) {
             if constexpr (PRO == PRO_NORM_SUM) {
@@ -165,7 +164,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
 #pragma unroll
                     for (int m = 0; m < M; ++m)
 #pragma unroll
-                        for (int j = 0; j < KJ; ++j) hv[m][j] += ld_act(a.part + ((size_t)m * np + p) * KC + threadIdx.x + 256 * j, coh);
+                        for (int j = 0; j < KJ; ++j) hv[m][j] += *(aux_ + ((size_t)m * np + p) * KC + threadIdx.x + 256 * j);
             }
             float ss[M];
 #pragma unroll
@@ -187,7 +186,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) {
                     const int i = threadIdx.x + 256 * j;
-                    if constexpr (PRO == PRO_NORM_SUM) { if (blockIdx.x == 0) st_act(a.h_out + (size_t)m * KC + i, hv[m][j], coh); }
+                    if constexpr (PRO == PRO_NORM_SUM) { if (blockIdx.x == 0) *(a.h_out + (size_t)m * KC + i) = hv[m][j]; }
                     store_x<XT>(xs, m * KC + i, hv[m][j] * inv * gv[j]);
                 }
             }
@@ -198,16 +197,16 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
                 for (int j = 0; j < KJ; ++j) store_x<XT>(xs, m * KC + threadIdx.x + 256 * j, hv[m][j]);
         }
     }
-    if constexpr (C == 0 || PRO == PRO_ATTN) {
+    if constexpr (C == 0) {
         // ---- generic prologue (any K) ----
         if constexpr (PRO == PRO_NORM || PRO == PRO_NORM_SUM) {
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                const float* hr = a.h + (size_t)m * K;
+                const float* hr = x_ + (size_t)m * K;
                 auto xin = [&](int i) -> float {
                     float v = hr[i];
                     if constexpr (PRO == PRO_NORM_SUM) {
-                        for (int p = 0; p < a.nsplit; ++p) v += a.part[((size_t)m * a.nsplit + p) * K + i];
+                        for (int p = 0; p < naux_; ++p) v += aux_[((size_t)m * naux_ + p) * K + i];
                     }
                     return v;
                 };
@@ -218,27 +217,11 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
                 for (int i = threadIdx.x; i < K; i += 256) {
                     const float v = xin(i);
                     if constexpr (PRO == PRO_NORM_SUM) { if (blockIdx.x == 0) a.h_out[(size_t)m * K + i] = v; }
-                    store_x<XT>(xs, m * K + i, v * inv * to_f(a.gamma[i]));
+                    store_x<XT>(xs, m * K + i, v * inv * to_f(gamma_[i]));
                 }
             }
         } else if constexpr (PRO == PRO_PLAIN) {
-            for (int i = threadIdx.x; i < M * K; i += 256) store_x<XT>(xs, i, a.xin[i]);
-        } else {  // PRO_ATTN: K == hq * d ; merge the split-KV records
-            const int RS = a.d + 2;
-            for (int i = threadIdx.x; i < M * K; i += 256) {
-                const int m = i / K, e = i % K, hh = e / a.d, dd = e % a.d;
-                const float* recs = a.part + ((size_t)m * a.hq + hh) * a.nsplit * RS;
-                float mx = -INFINITY;
-                for (int s = 0; s < a.nsplit; ++s) mx = fmaxf(mx, recs[(size_t)s * RS]);
-                float l = 0.f, o = 0.f;
-                for (int s = 0; s < a.nsplit; ++s) {
-                    const float* rec = recs + (size_t)s * RS;
-                    const float w = (rec[0] == -INFINITY) ? 0.f : __expf(rec[0] - mx);
-                    l = fmaf(rec[1], w, l);
-                    o = fmaf(rec[2 + dd], w, o);
-                }
-                store_x<XT>(xs, i, l > 0.f ? o / l : 0.f);
-            }
+            for (int i = threadIdx.x; i < M * K; i += 256) store_x<XT>(xs, i, x_[i]);
         }
     }
     __syncthreads();
@@ -298,8 +281,8 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int row = row_of(n0, r);
-                wrow[r] = reinterpret_cast<const WT*>(a.w) + (size_t)row * K;
-                srow[r] = a.wscale ? a.wscale + (size_t)(row >> 7) * (K >> 7) : nullptr;
+                wrow[r] = reinterpret_cast<const WT*>(w_) + (size_t)row * K;
+                srow[r] = wscale_ ? wscale_ + (size_t)(row >> 7) * (K >> 7) : nullptr;
             }
             if constexpr (FP8) gemv_rows_fp8<XT, M, R>(wrow, srow, xs, K, K, lane, acc);
             else gemv_rows<WT, XT, M, R>(wrow, xs, K, K, lane, acc);
@@ -317,7 +300,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
 #pragma unroll
                         for (int m = 0; m < M; ++m) {
                             const float gt = acc[r][m], up = acc[r + R / 2][m];
-                            st_act(a.out + (size_t)m * a.ld_out + n0 + r, gt / (1.0f + __expf(-gt)) * up, coh);
+                            *(a.out + (size_t)m * a.ld_out + n0 + r) = gt / (1.0f + __expf(-gt)) * up;
                         }
                     }
             } else {
@@ -328,12 +311,12 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
                         for (int m = 0; m < M; ++m) {
                             const size_t o = (size_t)m * a.ld_out + n0 + r;
                             if constexpr (EPI == EPI_RESID) {
-                                const float base = (C > 0 && g == wave) ? resv[r][m] : ld_act(a.res + o, coh);
-                                st_act(a.out + o, base + acc[r][m], coh);
+                                const float base = (C > 0 && g == wave) ? resv[r][m] : *(aux_ + o);
+                                *(a.out + o) = base + acc[r][m];
                             } else if constexpr (EPI == EPI_LOGITS) {
                                 a.out[o] = acc[r][m];          // read by later launches only: ordinary stores
                             } else {
-                                st_act(a.out + o, acc[r][m], coh);
+                                *(a.out + o) = acc[r][m];
                             }
                             if constexpr (EPI == EPI_LOGITS) {
                                 if (acc[r][m] > best_v[m]) { best_v[m] = acc[r][m]; best_i[m] = n0 + r; }
@@ -360,7 +343,6 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FusedArgs a, unsigned l
             a.amax_idx[(size_t)m * gridDim.x + blockIdx.x] = bi;
         }
     }
-    if constexpr (DUAL) dep_signal(a.dep);
     tls.end();
 }
 
@@ -383,14 +365,13 @@ __global__ void embed_kernel(const bf16* embed, const int32_t* tokens, float* h,
 // One workgroup per sequence (grid = M).  Every workgroup reads the step counter before it takes an arrival ticket
 // (step_counter[1]); the bump is made by whoever draws the last ticket, so it cannot overtake a read.  (One workgroup
 // for the whole chunk, a wave per sequence, took 25 us at M = 8 and 57 us at M = 16 - a dependent walk per sequence.)
-__global__ __launch_bounds__(256) void finalize_kernel(const float* amax_val, const int* amax_idx, int nblk,
+__global__ __launch_bounds__(256) void finalize_kernel(unsigned long long* tl, const float* amax_val, const int* amax_idx, int nblk,
                                                        int32_t* tokens, int32_t* positions, int32_t* token_log,
                                                        int32_t* step_counter, int log_width, int log_cap,
                                                        const bf16* embed, float* h, int H, int bump,
                                                        unsigned long long* clk_log, const float* rope_cos,
                                                        const float* rope_sin, float* cur_cos, float* cur_sin, int half,
-                                                       int max_seq, int M, const int32_t* sampled, unsigned* dep_epoch,
-                                                       unsigned long long* tl) {
+                                                       int max_seq, int M, const int32_t* sampled) {
     const TLStamp tls(tl);
     __shared__ float sv[4];
     __shared__ int si[4];
@@ -454,15 +435,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* amax_val, co
         cur_sin[(size_t)b * half + i] = rope_sin[(size_t)s_pos * half + i];
     }
     if (bump && threadIdx.x == 0) {
-        // dep_epoch: steps completed, the base of the dual chain's arrival-counter targets (never reset, unlike the log's
-        // step counter); every kernel of the NEXT step is launched behind this one
         if (M == 1) {
             step_counter[0] = step + 1;
-            if (dep_epoch) dep_epoch[0] += 1u;
         } else if (atomicAdd(&step_counter[1], 1) == M - 1) {   // every workgroup has read `step` before its own ticket
             atomicExch(&step_counter[1], 0);
             step_counter[0] = step + 1;
-            if (dep_epoch) dep_epoch[0] += 1u;
         }
     }
     tls.end();
@@ -485,15 +462,12 @@ struct AttnArgs {
     float* part;          // [B][Hq][nsplit][D+2]
     int nsplit;
     float* attn_direct;   // whole-context variant (nsplit == 1): normalised output [B][Hq][D], no merge launch
-    int* merge_counter;   // split path, in-kernel merge: [B][Hkv] arrival counters (null: separate attn_merge_kernel)
-    float* attn_merged;   //   ... and where the last-arriving workgroup of a kv head writes the merged output [B][Hq][D]
     // fused o_proj path
     const bf16* w_o;      // [H][Hq*D] (fp8 codes on the merged o_proj path with fp8 weights)
     const bf16* w_o_scale; // fp8 W_o: [H/128][Hq*D/128] block scales
     int H, rows_per_block;
     float* opart;         // [B][Hkv][H]
     bf16* attn_direct16;  // whole-context variant: bf16 output instead of attn_direct (batched MFMA o_proj reads it)
-    DepArgs dep;          // dual-chain step (attn_oproj_kernel only); all null otherwise
     // GQA groups other than the instantiated 1 / 2 / 4 query heads per kv head run as several launches over head chunks:
     // this launch serves query heads kvh * g_total + g_off + [0, G) of every kv head (ordinary launch: g_total = G, g_off = 0)
     int g_total, g_off;
@@ -516,17 +490,16 @@ struct NewTokenRaw {
     float4 cs[2], sn[2];           // RoPE row slice
 };
 
-template <int D, int G, bool COH = false>
+template <int D, int G>
 __device__ __forceinline__ void new_token_load(const AttnArgs& a, int b, int kvh, int lane, NewTokenRaw<G>& r) {
     constexpr int LPR = D / 8, HALF = D / 2;
     const int sub = lane % LPR;
     const float* row = a.qkv + (size_t)b * a.qkv_ld;
 #pragma unroll
     for (int g = 0; g < G + 2; ++g) {
-        // q/k/v come from the previous kernel of this step: sc1 loads in a dual chain (engine_common.cuh)
         const unsigned eoff = (g < G) ? (unsigned)(kvh * a.g_total + a.g_off + g) * D : (g == G ? (unsigned)(a.hq + kvh) * D : (unsigned)(a.hq + a.hkv + kvh) * D);
-        r.lo[g] = ld_act4(row, eoff + sub * 8, COH);
-        r.hi[g] = ld_act4(row, eoff + sub * 8 + 4, COH);
+        r.lo[g] = *reinterpret_cast<const float4*>(row + eoff + sub * 8);
+        r.hi[g] = *reinterpret_cast<const float4*>(row + eoff + sub * 8 + 4);
     }
     r.gq = r.gk = make_uint4(0, 0, 0, 0);
     if (a.q_gamma != nullptr) {
@@ -605,10 +578,10 @@ __device__ __forceinline__ void new_token_finish(const AttnArgs& a, int lane, co
     t.vbits = vb.raw;
 }
 
-template <int D, int G, bool COH = false>
+template <int D, int G>
 __device__ __forceinline__ void prepare_new_token(const AttnArgs& a, int b, int kvh, int pos, int lane, NewToken<D, G>& t) {
     NewTokenRaw<G> r;
-    new_token_load<D, G, COH>(a, b, kvh, lane, r);
+    new_token_load<D, G>(a, b, kvh, lane, r);
     new_token_finish<D, G>(a, lane, r, t);
 }
 
@@ -629,7 +602,7 @@ __device__ __forceinline__ void fold_new_token(const NewToken<D, G>& t, DecodeSt
 
 // split path: grid (nsplit, Hkv, batch)
 template <int D, int G, bool DIRECT>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned long long* tl) {
+__global__ __launch_bounds__(256) void attn_decode_kernel(unsigned long long* tl, AttnArgs a) {
     const TLStamp tls(tl);
     constexpr int LPR = D / 8, PPW = 64 / LPR, RS = D + 2;
     __shared__ __attribute__((aligned(16))) float lds[4 * PPW * G * RS];
@@ -644,7 +617,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
         // two dependent trips - 9.2 us against 6.x for 8 sequences).
         constexpr int U0 = 12;
         NewTokenRaw<G> raw;                 // issue order = arrival order: the few L2-resident q/k/v bytes first, then the K/V rows
-        new_token_load<D, G, false>(a, b, kvh, lane, raw);
+        new_token_load<D, G>(a, b, kvh, lane, raw);
         __builtin_amdgcn_sched_barrier(0);
         KVBatch<U0> kb0;
         kv_issue<D, U0, 4>(kb0, a.kcache + head_off, a.vcache + head_off, wid * PPW, a.max_seq - 1, lane);
@@ -679,7 +652,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
     const int chunk = decode_chunk_len(a.max_seq, a.nsplit, 4 * PPW);
     const int c0 = (int)blockIdx.x * chunk;
     NewTokenRaw<G> raw;
-    new_token_load<D, G, false>(a, b, kvh, lane, raw);
+    new_token_load<D, G>(a, b, kvh, lane, raw);
     __builtin_amdgcn_sched_barrier(0);
     KVBatch<U1> kb0;
     kv_issue<D, U1, 4>(kb0, a.kcache + head_off, a.vcache + head_off, c0 + wid * PPW, a.max_seq - 1, lane);
@@ -711,62 +684,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
     } else {
         decode_block_merge<D, G>(st, lds, a.part + (((size_t)b * a.hq + (size_t)kvh * a.g_total + a.g_off) * a.nsplit + blockIdx.x) * RS,
                                  (size_t)a.nsplit * RS, lane, wid);
-        if (a.merge_counter) {
-            // In-launch merge (saves the merge kernel and its boundary): publish this slice's records, take a ticket,
-            // and let the workgroup that draws the last ticket of its (sequence, kv head) combine all slices.
-            // Hand-off per the inter-workgroup recipe of the CDNA guide: every storing wave drains its stores, the
-            // workgroup meets, ONE agent-scope release, drain, relaxed ticket; the reducer: ONE agent-scope acquire,
-            // drain, barrier, then plain loads.  Correct for any placement of the slices over XCDs.
-            __shared__ int s_last;
-            __shared__ float w_s[G][64];
-            __shared__ float inv_l[G];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            int* cnt = a.merge_counter + (size_t)b * a.hkv + kvh;
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const int prev = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_last = prev == a.nsplit - 1;
-            }
-            __syncthreads();
-            if (!s_last) { tls.end(); return; }
-            if (threadIdx.x == 0) {
-                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next layer's launch
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            // same arithmetic, in the same order, as attn_merge_kernel: the two paths are bit-identical
-            const float* hrecs = a.part + ((size_t)b * a.hq + (size_t)kvh * G) * a.nsplit * RS;
-            if (wid < G) {
-                const float* recs = hrecs + (size_t)wid * a.nsplit * RS;
-                const int sc = min(lane, a.nsplit - 1);
-                float m = recs[(size_t)sc * RS], l = recs[(size_t)sc * RS + 1];
-                if (lane >= a.nsplit) { m = -INFINITY; l = 0.f; }
-                const float mx = wave_max(m);
-                const float w = (m == -INFINITY) ? 0.f : __expf(m - mx);
-                const float tot = wave_sum(w * l);
-                w_s[wid][lane] = w;
-                if (lane == 0) inv_l[wid] = tot > 0.f ? 1.0f / tot : 0.f;
-            }
-            __syncthreads();
-            for (int e = threadIdx.x; e < G * D; e += 256) {
-                const int g = e / D, d = e % D;
-                const float* recs = hrecs + (size_t)g * a.nsplit * RS;
-                float o = 0.f;
-                int s = 0;
-                for (; s + 8 <= a.nsplit; s += 8) {
-                    float v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = recs[(size_t)(s + u) * RS + 2 + d];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) o = fmaf(w_s[g][s + u], v[u], o);
-                }
-                for (; s < a.nsplit; ++s) o = fmaf(w_s[g][s], recs[(size_t)s * RS + 2 + d], o);
-                a.attn_merged[((size_t)b * a.hq + (size_t)kvh * G) * D + e] = o * inv_l[g];
-            }
-        }
     }
     tls.end();
 }
@@ -776,7 +693,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a, unsigned l
 // owns record s's (m, l): one load each, a wave max and a wave sum give the weights; then every thread sums its
 // element over the records with independent loads.
 template <int D>
-__global__ void attn_merge_kernel(const float* part, float* attn, int hq, int nsplit, unsigned long long* tl) {
+__global__ void attn_merge_kernel(unsigned long long* tl, const float* part, float* attn, int hq, int nsplit) {
     const TLStamp tls(tl);
     __shared__ float w_s[64];
     __shared__ float inv_l;
@@ -811,8 +728,8 @@ __global__ void attn_merge_kernel(const float* part, float* attn, int hq, int ns
 // fused path: grid ((H / rows_per_block) * Hkv, 1, batch), 256 threads.  Every workgroup of a KV head recomputes
 // that head's (short-context) attention from L2-resident K/V, then multiplies it with ITS slice of W_o
 // (rows_per_block output rows x G*D columns), whose loads were issued before anything else.
-template <int D, int G, bool DUAL = false>
-__global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a, unsigned long long* tl) {
+template <int D, int G>
+__global__ __launch_bounds__(256) void attn_oproj_kernel(unsigned long long* tl, AttnArgs a) {
     const TLStamp tls(tl);
 #ifdef PGK_PHASE_STAMPS
     if (threadIdx.x == 0) g_phase_tl = tl;      // same value from every workgroup of the launch
@@ -839,16 +756,13 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a, unsigned lo
     // Issue order = arrival order (vector memory returns in order): first the few L2-resident bytes the new token's
     // q/k/v need, then the cached K/V rows, last the W_o slice that is only consumed at the very end.  (The first
     // version issued W_o and K/V first: the q/k/v row then arrived behind ~1.4 KiB per lane of HBM traffic and the
-    // norm / RoPE work started 2.9 us into the workgroup - in-kernel stamps, tools/phase_stamps.py.)  In a dual chain
-    // q/k/v do not exist yet when the workgroup starts: the streams go first, then the wait, then the row.
+    // norm / RoPE work started 2.9 us into the workgroup - in-kernel stamps, tools/phase_stamps.py.)
     const size_t head_off = (((size_t)b * a.hkv + kvh) * a.max_seq) * D;
     uint4 pre[PRE];
     KVBatch<U0> kb0;
     NewTokenRaw<G> raw;
-    if constexpr (!DUAL) {
-        new_token_load<D, G, false>(a, b, kvh, lane, raw);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    new_token_load<D, G>(a, b, kvh, lane, raw);
+    __builtin_amdgcn_sched_barrier(0);
     // first KV batch: U0 position-groups per wave = positions [0, U0*NWV*PPW); addresses do not depend on
     // the context length (clamped), so these loads share the round trip of everything else in this kernel
     kv_issue<D, U0, NWV>(kb0, a.kcache + head_off, a.vcache + head_off, wid * PPW, a.max_seq - 1, lane);
@@ -858,10 +772,6 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a, unsigned lo
     __builtin_amdgcn_sched_barrier(0);
     const int pos = load_uniform_i32(a.positions + b);     // scalar path: not queued behind the 50-odd vector loads above
     tls.phase(0);
-    if constexpr (DUAL) {
-        dep_wait(a.dep);
-        new_token_load<D, G, true>(a, b, kvh, lane, raw);
-    }
     NewToken<D, G> t;
     new_token_finish<D, G>(a, lane, raw, t);
     if (rb == 0 && pos < a.max_seq && wid == 0 && lane < LPR) {
@@ -895,10 +805,9 @@ __global__ __launch_bounds__(256) void attn_oproj_kernel(AttnArgs a, unsigned lo
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc = fmaf(wf[j], xf[j], acc);
         acc = group_sum<LPW>(acc);
-        if (lr == 0) st_act(outp + row, acc, DUAL);
+        if (lr == 0) outp[row] = acc;
     }
     tls.phase(4);
-    if constexpr (DUAL) dep_signal(a.dep);
     tls.end();
 }
 
@@ -929,7 +838,7 @@ __device__ __forceinline__ int am_voff(int row, int ch) { return row * 256 + ((c
 // OPROJ = false: the whole-context BATCH attention (one workgroup per (sequence, kv head), grid (Hkv, 1, batch)): the same
 // kernel without the W_o slice - the normalised heads leave as bf16 (attn_direct16) or fp32 (attn_direct) rows.
 template <int G, bool OPROJ = true>
-__global__ __launch_bounds__(256) void attn_oproj_mfma_kernel(AttnArgs a, unsigned long long* tl) {
+__global__ __launch_bounds__(256) void attn_oproj_mfma_kernel(unsigned long long* tl, AttnArgs a) {
     const TLStamp tls(tl);
     typedef __bf16 am_bf16x8 __attribute__((ext_vector_type(8)));
     typedef float am_f32x4 __attribute__((ext_vector_type(4)));
@@ -1237,7 +1146,7 @@ __global__ __launch_bounds__(256) void attn_oproj_mfma_kernel(AttnArgs a, unsign
 // one launch and one dependent-kernel gap less per layer (context 2048, w8a16: the pair took 1.95 + 1.3 + 1.74 us of
 // every 23.8 us layer; profiles/r02_config3_timeline.json).  W_o bf16 or fp8 (16 codes per lane, block scale in registers).
 template <int D, int G, bool FP8>
-__global__ __launch_bounds__(256) void attn_merge_oproj_kernel(AttnArgs a, unsigned long long* tl) {
+__global__ __launch_bounds__(256) void attn_merge_oproj_kernel(unsigned long long* tl, AttnArgs a) {
     const TLStamp tls(tl);
     constexpr int RS = D + 2, GD = G * D;
     constexpr int NWT = FP8 ? 16 : 8;                // weights per 16-byte load
@@ -1561,27 +1470,21 @@ struct Engine {
     const bf16 *embed, *lm_head, *final_norm;
     std::vector<pgk_layer_weights_t> layers;
     int nsplit = 1, lm_blocks = 1, lm_cap = 1, log_cap = 4096;
-    bool batched_mfma = true;   // chunks of 3 and 5..16 sequences use engine_batched.cuh (PGK_BATCHED_MFMA=0: GEMV kernels only, =2: from 3 up, =3: from 9 up)
-    bool tiled_norm_fused = false;  // PGK_TILED_NORM_FUSED=1: fold the RMSNorms of the 17..64-sequence path into their neighbours (measured slower: DESIGN.md)
+    bool batched_mfma = true;   // chunks of 3 and 5..16 sequences use engine_batched.cuh (PGK_BATCHED_MFMA=0: GEMV kernels only, =2: from 3 up)
     int batched_min = 5, batched_max = 64;   // PGK_BATCHED_MAX=16: chunks of at most 16 sequences (one weight pass per chunk), the A/B switch of the tiled kernels
-    int cu_count = 256, attn_waves = 0;   // attn_waves: PGK_ATTN_WAVES override of the workgroups-per-CU target (0 = by batch)
-    int* merge_cnt = nullptr;      // PGK_ATTN_INKERNEL_MERGE=1: split-KV attention merges inside the launch (last arriver); default: merge kernel
-    bool attn_direct_ok = false;
+    int cu_count = 256;
+    bool short_path = true;     // contexts <= SHORT_CTX take the whole-context attention kernels (PGK_FUSED_ATTN=0: the split-KV sequence at every context)
+    int pos_hi = -1;            // host-side upper bound of the largest position the next step sees (-1: unknown); selects the sequence, see step_is_short
     // in-graph stochastic sampling (pgk_engine_set_sampling): temperature <= 0 keeps greedy argmax
     float sample_temperature = 0.f, sample_top_p = 1.f;
     int sample_top_k = 0, u_cap = 0, u_alloc_rows = 0;   // u_cap: rows in use (ring length); u_alloc_rows: rows allocated
     float* u_ring = nullptr;       // [u_cap][max_batch] uniforms, row = step counter % u_cap
     void* sample_scratch = nullptr;   // top-k candidate keys (ops_sampling.hip), sized for max_batch rows
     size_t sample_scratch_cap = 0;
-    int32_t* sampled = nullptr;    // [max_batch]   // max_seq <= 512: batch attention in one workgroup per (sequence, kv head)
-#ifdef PGK_ABLATION
-    int skip_attn = 0;         // -DPGK_ABLATION builds only: PGK_DEBUG_SKIP & 16 drops the attention launch (timing ablation, wrong tokens)
-#else
-    static constexpr int skip_attn = 0;
-#endif
-    bool fused_attn = false;   // attn + o_proj in one kernel (short contexts, bf16 W_o)
-    bool attn_mfma_direct = false;   // the same kernel without the W_o slice as the whole-context batch attention while its workgroups (96 KB of LDS: one per CU) fit one round - batch x Hkv <= CUs; beyond (batch 64: 1.316 vs 1.258 ms) and with PGK_ATTN_MFMA_DIRECT=0: attn_decode_kernel
-    bool attn_mfma = false;    // ... with Q.K^T and P.V on the matrix pipe from LDS-staged K/V (head_dim 128; PGK_ATTN_MFMA=0: the dot2 kernel)
+    int32_t* sampled = nullptr;    // [max_batch]
+    bool fused_attn = false;   // one or two sequences at short context: attn + o_proj in one kernel (bf16 W_o, shapes that tile)
+    bool attn_mfma = false;    // ... with Q.K^T and P.V on the matrix pipe from LDS-staged K/V (head_dim 128; PGK_ATTN_MFMA=0: the dot2 kernels); also the whole-context
+                               // batch attention while its workgroups (96 KB of LDS: one per CU) fit one round - batch x Hkv <= CUs (beyond: attn_decode_kernel, batch 64 1.258 vs 1.316 ms)
     bool merged_oproj = false; // long contexts / fp8 W_o, one or two sequences: split-KV merge + o_proj in one kernel (PGK_MERGED_OPROJ=0: merge kernel + GEMV)
     int moproj_rows = 32;
     int oproj_rows = 32;       // W_o rows per workgroup on the fused path
@@ -1596,13 +1499,6 @@ struct Engine {
           *amax_val = nullptr;
     int* amax_idx = nullptr;
     unsigned long long* clk_log = nullptr;
-    // dual-chain step (engine_common.cuh): arrival counters [4 L][DEP_SHARDS x DEP_STRIDE], the epoch word, the error word,
-    // and the second capture branch
-    unsigned *dep_cnt = nullptr, *dep_epoch = nullptr, *dep_err = nullptr;
-    bool gateup_r4 = false;         // PGK_GATEUP_R4=1: 4 rows per wave in the batch-1 gate/up GEMV (half the workgroups)
-    bool dual_ok = false;           // PGK_DUAL_CHAIN=1 and the shapes suit it (opt-in: measured no faster)
-    hipStream_t st2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t kv_bytes = 0, ws_bytes = 0;
     // fragment-major copies of the layer weights for prompts of <= 128 tokens (ops_pkgemm.hip); PGK_PACKED_PREFILL=0: none
     struct PackedLayer { bf16 *qkv = nullptr, *o = nullptr, *gate_up = nullptr, *down = nullptr; };
@@ -1619,9 +1515,10 @@ struct Engine {
     size_t pf_bytes = 0;
     int32_t* pf_tokens = nullptr;
     int pf_tokens_cap = 0;
-    // captured step
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
+    // captured step: [0] the long-context launch sequence, [1] the short-context one (when the engine has both)
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t exec[2] = {nullptr, nullptr};
+    int graph_launches[2] = {0, 0};
     int graph_batch = 0;
     int launches_per_step = 0;
     std::vector<void*> allocs;
@@ -1639,19 +1536,12 @@ static pgk_status dev_alloc(Engine* e, void** p, size_t bytes, size_t* acct) {
 }
 
 
-static thread_local int g_last_grid = 0;     // workgroups of the most recent fused / attention launch (dual-chain wiring)
-
 template <class WT, class XT, int M, int R, int PRO, int EPI, int C>
 static pgk_status launch_fused_c(const FusedArgs& a, int n_out, hipStream_t st, int force_grid) {
     constexpr int OUT_PER_TRIP = (EPI == EPI_SWIGLU) ? R / 2 : R;
     const size_t lds = (size_t)M * a.K * sizeof(XT);
     PGK_REQUIRE(lds <= 156 * 1024, "engine: %d activation rows of K=%d do not fit LDS", M, a.K);
-    auto kfn = &fused_gemv_kernel<WT, XT, M, R, PRO, EPI, C, false>;
-    constexpr bool DUAL_OK = C > 0 && M == 1 && std::is_same<WT, bf16>::value && std::is_same<XT, float>::value && EPI != EPI_LOGITS && PRO != PRO_ATTN;
-    if (a.dep.sig_cnt || a.dep.wait_cnt) {
-        if constexpr (DUAL_OK) kfn = &fused_gemv_kernel<WT, XT, M, R, PRO, EPI, C, true>;
-        else return set_error(PGK_ERR_UNSUPPORTED, "engine: no dual-chain instance of this GEMV (M=%d, K=%d)", M, a.K);
-    }
+    auto kfn = &fused_gemv_kernel<WT, XT, M, R, PRO, EPI, C>;
     static bool attr_done = false;
     if (lds > 48 * 1024 && !attr_done) {
         PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
@@ -1659,8 +1549,10 @@ static pgk_status launch_fused_c(const FusedArgs& a, int n_out, hipStream_t st, 
     }
     int grid = force_grid ? force_grid : ceil_div(n_out, OUT_PER_TRIP * 4);
     if (grid > 1024) grid = 1024;
-    g_last_grid = grid;
-    PGK_CHECK_HIP(launch_k(kfn, dim3(grid), dim3(256), lds, st, a));
+    const float* x = (PRO == PRO_PLAIN) ? a.xin : a.h;
+    const float* aux = (PRO == PRO_NORM_SUM) ? a.part : a.res;
+    const int naux = (PRO == PRO_NORM_SUM) ? a.nsplit : a.ld_out;
+    PGK_CHECK_HIP(launch_k(kfn, dim3(grid), dim3(256), lds, st, a.w, a.wscale, x, a.gamma, aux, a.N, naux, a));
     return PGK_OK;
 }
 
@@ -1711,9 +1603,12 @@ static hipError_t launch_attn_mfma(dim3 grid, hipStream_t st, const AttnArgs& a)
     return launch_k(attn_oproj_mfma_kernel<G, OPROJ>, grid, dim3(256), lds, st, a);
 }
 
+// `fused`: attention + o_proj partials in one kernel (one or two sequences at short context); `direct`: one workgroup per
+// (sequence, kv head) walks the whole (short) context and writes the normalised output - no merge launch; otherwise
+// split-KV slices, then `merged` (merge + o_proj partials in one launch) or the merge kernel.
 template <int D>
-static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, hipStream_t st, bool direct_bf16 = false,
-                              const DepArgs* dep = nullptr, bool merged = false) {
+static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, bool direct, hipStream_t st, bool direct_bf16 = false,
+                              bool merged = false) {
     const auto& c = e->cfg;
     const auto& L = e->layers[layer];
     const int G = c.num_heads / c.num_kv_heads;
@@ -1734,32 +1629,25 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
     // for a free CU and adds a tail: 33 slices x 8 heads measured 5 % slower than 32 at context 2048), never more than
     // the workspace was sized for (e->nsplit: ~64 positions per slice at the full cache length)
     // (batches stream enough KV bytes to want two workgroups per CU: measured 22.1 vs 24.6 us at 8 x 2048 positions)
-    int ns = e->cu_count * (e->attn_waves > 0 ? e->attn_waves : (m >= 4 ? 2 : 1)) / (c.num_kv_heads * m);
+    int ns = e->cu_count * (m >= 4 ? 2 : 1) / (c.num_kv_heads * m);
     ns = ns < 1 ? 1 : (ns > e->nsplit ? e->nsplit : ns);
     // slices are cut by absolute position in whole position-group steps: launch only as many as the cache length needs
     a.nsplit = ceil_div(c.max_seq_len, decode_chunk_len(c.max_seq_len, ns, 4 * (64 / (D / 8))));
     a.w_o = (const bf16*)L.w_o; a.w_o_scale = (const bf16*)L.s_o; a.H = c.hidden_size; a.rows_per_block = e->oproj_rows;
     a.opart = e->opart ? e->opart + (size_t)b0 * c.num_kv_heads * c.hidden_size : nullptr;
-    // batches at short context: one workgroup per (sequence, kv head) walks the whole context and writes the
-    // normalised output itself - Hkv * m workgroups, and the merge launch disappears
-    const bool direct = !fused && e->attn_direct_ok && m >= 3;
     if (direct) {
         a.nsplit = 1;
         a.attn_direct = e->attnv + (size_t)b0 * c.num_heads * D;
         if (direct_bf16) a.attn_direct16 = e->attnv16 + (size_t)b0 * c.num_heads * D;
     }
-    const bool inmerge = !fused && !direct && e->merge_cnt != nullptr;
-    if (inmerge) { a.merge_counter = e->merge_cnt + (size_t)b0 * c.num_kv_heads; a.attn_merged = e->attnv + (size_t)b0 * c.num_heads * D; }
     dim3 grid = fused ? dim3((c.hidden_size / e->oproj_rows) * c.num_kv_heads, 1, m) : dim3(a.nsplit, c.num_kv_heads, m);
-    if (dep && fused) a.dep = *dep;
-    g_last_grid = (int)(grid.x * grid.y * grid.z);
     hipError_t he = hipSuccess;
     a.g_total = G;
     a.g_off = 0;
     if (G != 1 && G != 2 && G != 4) {
         // any other group size (Qwen2.5-7B: 28 / 4 = 7): chunks of 4, 2 and 1 query heads per kv head, one launch each -
         // every chunk re-reads the kv head's K/V rows, which is what the reference's GQA-expanded cache costs for ALL heads
-        PGK_REQUIRE(!fused && !inmerge, "engine: fused / in-launch-merge attention needs a GQA group of 1, 2 or 4");
+        PGK_REQUIRE(!fused, "engine: fused attention needs a GQA group of 1, 2 or 4");
         for (int off = 0; off < G;) {
             const int gc = (G - off >= 4) ? 4 : ((G - off >= 2) ? 2 : 1);
             a.g_off = off;
@@ -1772,10 +1660,9 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
     } else {
 #define PGK_ATTN(GG)                                                               \
     case GG:                                                                       \
-        if (fused && a.dep.sig_cnt) he = launch_k(attn_oproj_kernel<D, GG, true>, grid, dim3(256), 0, st, a);   \
-        else if (fused && D == 128 && e->attn_mfma) he = launch_attn_mfma<GG>(grid, st, a);         \
-        else if (fused) he = launch_k(attn_oproj_kernel<D, GG, false>, grid, dim3(256), 0, st, a);  \
-        else if (direct && D == 128 && e->attn_mfma_direct && m * (int)c.num_kv_heads <= e->cu_count) he = launch_attn_mfma<GG, false>(dim3(c.num_kv_heads, 1, m), st, a); \
+        if (fused && D == 128 && e->attn_mfma) he = launch_attn_mfma<GG>(grid, st, a);              \
+        else if (fused) he = launch_k(attn_oproj_kernel<D, GG>, grid, dim3(256), 0, st, a);         \
+        else if (direct && D == 128 && e->attn_mfma && m * (int)c.num_kv_heads <= e->cu_count) he = launch_attn_mfma<GG, false>(dim3(c.num_kv_heads, 1, m), st, a); \
         else if (direct) he = launch_k(attn_decode_kernel<D, GG, true>, grid, dim3(256), 0, st, a); \
         else he = launch_k(attn_decode_kernel<D, GG, false>, grid, dim3(256), 0, st, a);            \
         break;
@@ -1788,7 +1675,7 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
     }
     if (merged) {
         // split-KV merge + o_proj partial products in one launch (attn_merge_oproj_kernel)
-        PGK_REQUIRE(!fused && !direct && !inmerge && (G == 1 || G == 2 || G == 4), "engine: merged o_proj on an unsupported attention path");
+        PGK_REQUIRE(!fused && !direct && (G == 1 || G == 2 || G == 4), "engine: merged o_proj on an unsupported attention path");
         mark(KC_OPROJ);
         a.rows_per_block = e->moproj_rows;
         const dim3 g2((c.hidden_size / e->moproj_rows) * c.num_kv_heads, 1, m);
@@ -1801,7 +1688,7 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, h
         switch (G) { PGK_MO(1) PGK_MO(2) PGK_MO(4) default: break; }
 #undef PGK_MO
         PGK_CHECK_HIP(he);
-    } else if (!fused && !direct && !inmerge) {
+    } else if (!fused && !direct) {
         PGK_CHECK_HIP(launch_k(attn_merge_kernel<D>, dim3(c.num_heads, m), dim3(D), 0, st, (const float*)a.part,
                                e->attnv + (size_t)b0 * c.num_heads * D, (int)c.num_heads, (int)a.nsplit));
     }
@@ -1820,43 +1707,23 @@ static pgk_status engine_sample(Engine* e, int b0, int M, hipStream_t st) {
                             e->sample_top_p, e->u_ring + b0, e->u_cap, e->cfg.max_batch, e->step_counter, e->sampled + b0, e->sample_scratch, st);
 }
 
-// `dual`: wire the 4 L layer kernels into the dual chain (engine_common.cuh) - every kernel waits for its predecessor on
-// a device counter instead of relying on stream order.  With st2 != st (graph capture) consecutive kernels alternate
-// between the two capture branches and overlap; with st2 == st (eager) the same kernels run back to back and every wait
-// is already satisfied.  Only single-chunk steps on the fused short-context path qualify (decode_step_impl).
+// One decode step for sequences [b0, b0+M); `last` = this is the step's last chunk (bumps the step counter).
+// `short_ctx`: every sequence of the step has at most SHORT_CTX positions - one or two sequences then take the fused
+// attention + o_proj kernel (4 L + 2 launches); otherwise split-KV slices + merge/o_proj (5 L + 2).  Both are correct at
+// any context: the choice follows the context of the step, not the capacity of the cache (pgk_engine_replay).
 template <class WT, class XT, int M>
-static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int* launches, bool dual = false, hipStream_t st2 = nullptr) {
+static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int* launches, bool short_ctx) {
     const auto& c = e->cfg;
     const int H = c.hidden_size, I = c.intermediate_size, D = c.head_dim, QD = c.num_heads * D, NQKV = e->qkv_dim();
     float* h = e->h + (size_t)b0 * H;
     float* h2 = e->h2 + (size_t)b0 * H;
     // fused attention+o_proj recomputes a KV head's attention in every row-slice workgroup: right for one or
     // two sequences at short context, wasteful for a batch - batches take the split-KV path.
-    const bool fused = e->fused_attn && M <= 2;
-    dual = dual && fused && !e->skip_attn;
+    const bool fused = e->fused_attn && short_ctx && M <= 2;
     // long contexts (or fp8 W_o): split-KV slices, then merge + o_proj partials in one launch; the gate/up prologue adds them
-    const bool merged = !fused && M <= 2 && e->merged_oproj && !e->merge_cnt;
+    const bool merged = !fused && M <= 2 && e->merged_oproj;
     const bool partials = fused || merged;
-    const bool two = dual && st2 && st2 != st;
-    hipStream_t sA = st, sB = two ? st2 : st;
-    if (two) {   // fork: the second branch starts behind everything already enqueued on the first
-        PGK_CHECK_HIP(hipEventRecord(e->ev_fork, st));
-        PGK_CHECK_HIP(hipStreamWaitEvent(st2, e->ev_fork, 0));
-    }
-    unsigned prev_wgs = 0;
-    int kidx = 0;
-    auto wire = [&]() -> DepArgs {
-        DepArgs d{};
-        if (dual) {
-            d.sig_cnt = e->dep_cnt + (size_t)kidx * DEP_SHARDS * DEP_STRIDE;
-            d.wait_cnt = kidx > 0 ? e->dep_cnt + (size_t)(kidx - 1) * DEP_SHARDS * DEP_STRIDE : nullptr;
-            d.wait_per_step = prev_wgs;
-            d.epoch = e->dep_epoch;
-            d.err = e->dep_err;
-        }
-        return d;
-    };
-    auto launched = [&]() { prev_wgs = (unsigned)g_last_grid; ++kidx; };
+    const bool direct = !fused && short_ctx && M >= 3;
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& L = e->layers[l];
         FusedArgs a{};
@@ -1865,17 +1732,11 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
         a.w = L.w_qkv; a.wscale = (const bf16*)L.s_qkv; a.N = NQKV; a.K = H;
         a.h = h; a.gamma = (const bf16*)L.attn_norm; a.eps = c.norm_eps;
         a.out = e->qkv + (size_t)b0 * NQKV; a.ld_out = NQKV;
-        a.dep = wire();
-        if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM, EPI_STORE>(a, NQKV, sA)) return r;
-        launched();
+        if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM, EPI_STORE>(a, NQKV, st)) return r;
         mark(KC_ATTN);
         // 2. attention (QK-norm, RoPE, KV write fused; on the fused path also the o_proj partial products)
-        if (!e->skip_attn) {
-            const DepArgs d = wire();
-            if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, fused, sB, false, &d, merged)) return r; }
-            else { if (pgk_status r = launch_attn<64>(e, l, b0, M, fused, sB, false, &d, merged)) return r; }
-            launched();
-        }
+        if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, fused, direct, st, false, merged)) return r; }
+        else { if (pgk_status r = launch_attn<64>(e, l, b0, M, fused, direct, st, false, merged)) return r; }
         const float* mlp_in = h;
         if (merged) *launches += 1;          // the merge + o_proj launch
         if (!partials) {
@@ -1886,8 +1747,7 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
             a.xin = e->attnv + (size_t)b0 * QD;
             a.res = h; a.out = h; a.ld_out = H;
             if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_PLAIN, EPI_RESID>(a, H, st)) return r;
-            launched();
-            *launches += (((e->attn_direct_ok && M >= 3) || e->merge_cnt) ? 1 : 2) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;   // o_proj (+ the merge kernel unless attention normalised in place)
+            *launches += (direct ? 1 : 2) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;   // o_proj (+ the merge kernel unless attention normalised in place)
         }
         // 4. act = silu(Wg x) * (Wu x), x = rmsnorm(h [+ sum of o_proj partials])
         mark(KC_GATEUP);
@@ -1899,19 +1759,13 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
         if constexpr (M <= 2) {   // per-kv-head o_proj partials only ever exist for one or two sequences per chunk
             if (partials) {
                 a.part = e->opart + (size_t)b0 * c.num_kv_heads * H; a.nsplit = c.num_kv_heads; a.h_out = h2;
-                a.dep = wire();
-                // dual chain: 4 rows per wave (half the workgroups, same per-row arithmetic) so that this kernel, spinning on
-                // every CU, still leaves the 256-register slots the attention kernel's workgroups need
-                if (dual || e->gateup_r4) { if (pgk_status r = launch_fused<WT, XT, M, 4, PRO_NORM_SUM, EPI_SWIGLU>(a, I, sA)) return r; }
-                else if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM_SUM, EPI_SWIGLU>(a, I, sA)) return r;
-                launched();
+                if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM_SUM, EPI_SWIGLU>(a, I, st)) return r;
                 mlp_in = h2;
                 done_gateup = true;
             }
         }
         if (!done_gateup) {
             if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM, EPI_SWIGLU>(a, I, st)) return r;
-            launched();
         }
         // 5. h = mlp_in + Wd . act
         mark(KC_DOWN);
@@ -1919,14 +1773,8 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
         a.w = L.w_down; a.wscale = (const bf16*)L.s_down; a.N = H; a.K = I;
         a.xin = e->act + (size_t)b0 * I;
         a.res = mlp_in; a.out = h; a.ld_out = H;
-        a.dep = wire();
-        if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_PLAIN, EPI_RESID>(a, H, sB)) return r;
-        launched();
+        if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_PLAIN, EPI_RESID>(a, H, st)) return r;
         *launches += 4;
-    }
-    if (two) {   // join: lm_head and everything after it are ordinary successors of BOTH branches
-        PGK_CHECK_HIP(hipEventRecord(e->ev_join, st2));
-        PGK_CHECK_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
     }
     // logits = E . rmsnorm(h)  (lm_head stays bf16 even when the linears are fp8)
     mark(KC_LMHEAD);
@@ -1947,7 +1795,7 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
                                        e->lm_blocks, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
                                        e->cfg.max_batch, e->log_cap, e->embed, h, H, last ? 1 : 0, b0 == 0 ? e->clk_log : nullptr,
                                        e->rope_cos, e->rope_sin, e->cur_cos + (size_t)b0 * (D / 2), e->cur_sin + (size_t)b0 * (D / 2),
-                                       D / 2, c.max_seq_len, M, sampled, dual ? e->dep_epoch : (unsigned*)nullptr));
+                                       D / 2, c.max_seq_len, M, sampled));
     *launches += 2;
     return PGK_OK;
 }
@@ -1957,19 +1805,14 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
 // context); 17..64 sequences run the M-tiled kernels - each weight byte is still read ONCE per step - on rows that one
 // small launch per norm has already normalised to bf16 (7 L + 3 launches).  Attention is per sequence either way.
 template <class WT>
-static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipStream_t st, int* launches) {
+static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipStream_t st, int* launches, bool short_ctx) {
     const auto& c = e->cfg;
     constexpr bool FP8 = std::is_same<WT, fp8e4m3>::value;
     const int H = c.hidden_size, I = c.intermediate_size, D = c.head_dim, QD = c.num_heads * D, NQKV = e->qkv_dim();
     float* h = e->h + (size_t)b0 * H;
     bf16* x16 = e->x16 + (size_t)b0 * H;
     const bool tiled = M > 16;
-    const bool direct = e->attn_direct_ok && M >= 3;
-    // tiled path, opt-in experiment: RMSNorm folded into its neighbours (FusedArgs: hb16_out / ss_out on the producer of the
-    // residual stream, ss_in on the consumer); default: one small norm_rows_bf16 launch per RMSNorm, which measured faster
-    // (batch 64: 1.88-1.95 ms per step against 2.07-2.09 - every consumer workgroup re-derives the 64 row statistics)
-    const bool nf = tiled && e->tiled_norm_fused;
-    const int ss_n = batched_tiled_groups(H, EPI_RESID);
+    const bool direct = short_ctx && M >= 3;
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& L = e->layers[l];
         FusedArgs a{};
@@ -1978,14 +1821,14 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
         a.h = h; a.gamma = (const bf16*)L.attn_norm; a.eps = c.norm_eps;
         a.out = e->qkv + (size_t)b0 * NQKV; a.ld_out = NQKV;
         if (tiled) {
-            if (nf && l > 0) { a.ss_in = e->ss_part; a.ss_n = ss_n; }      // x16 / ss_part were left by the previous layer's down_proj
-            else { if (pgk_status r = norm_rows_bf16(h, a.gamma, x16, M, H, c.norm_eps, st)) return r; *launches += 1; }
+            if (pgk_status r = norm_rows_bf16(h, a.gamma, x16, M, H, c.norm_eps, st)) return r;
+            *launches += 1;
             a.xin16 = x16;
         }
         if (pgk_status r = batched_proj(FP8, tiled ? PRO_PLAIN : PRO_NORM, EPI_STORE, a, M, st)) return r;
         mark(KC_ATTN);
-        if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, false, st, true)) return r; }
-        else { if (pgk_status r = launch_attn<64>(e, l, b0, M, false, st, true)) return r; }
+        if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, false, direct, st, true)) return r; }
+        else { if (pgk_status r = launch_attn<64>(e, l, b0, M, false, direct, st, true)) return r; }
         mark(KC_OPROJ);
         a = FusedArgs{};
         a.w = L.w_o; a.wscale = (const bf16*)L.s_o; a.N = H; a.K = QD;
@@ -1997,7 +1840,6 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
             a.xin16 = e->attnv16 + (size_t)b0 * QD;
             *launches += 1;
         }
-        if (nf) { a.hb16_out = x16; a.gamma_next = (const bf16*)L.mlp_norm; a.ss_out = e->ss_part; }
         if (pgk_status r = batched_proj(FP8, PRO_PLAIN, EPI_RESID, a, M, st)) return r;
         mark(KC_GATEUP);
         a = FusedArgs{};
@@ -2006,8 +1848,8 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
         a.out = e->act + (size_t)b0 * I; a.ld_out = I;
         a.out16 = e->act16 + (size_t)b0 * I;        // SiLU(g) * u leaves as bf16: down_proj rounds it to bf16 anyway
         if (tiled) {
-            if (nf) { a.ss_in = e->ss_part; a.ss_n = ss_n; }
-            else { if (pgk_status r = norm_rows_bf16(h, a.gamma, x16, M, H, c.norm_eps, st)) return r; *launches += 1; }
+            if (pgk_status r = norm_rows_bf16(h, a.gamma, x16, M, H, c.norm_eps, st)) return r;
+            *launches += 1;
             a.xin16 = x16;
         }
         if (pgk_status r = batched_proj(FP8, tiled ? PRO_PLAIN : PRO_NORM, EPI_SWIGLU, a, M, st)) return r;
@@ -2017,11 +1859,8 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
         a.xin = e->act + (size_t)b0 * I;
         a.xin16 = e->act16 + (size_t)b0 * I;
         a.res = h; a.out = h; a.ld_out = H;
-        if (nf) {
-            if (l + 1 < c.num_layers) { a.hb16_out = x16; a.ss_out = e->ss_part; a.gamma_next = (const bf16*)e->layers[l + 1].attn_norm; }
-        }
         if (pgk_status r = batched_proj(FP8, PRO_PLAIN, EPI_RESID, a, M, st)) return r;
-        *launches += ((direct || e->merge_cnt) ? 5 : 6) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;
+        *launches += (direct ? 5 : 6) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;
     }
     const int nblk = ceil_div(c.vocab_size, 16) < 2048 ? ceil_div(c.vocab_size, 16) : 2048;
     mark(KC_LMHEAD);
@@ -2048,7 +1887,7 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
     PGK_CHECK_HIP(launch_k(finalize_kernel, dim3(M), dim3(256), 0, st, a.amax_val, a.amax_idx, nblk, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
                                        e->cfg.max_batch, e->log_cap, e->embed, h, H, last ? 1 : 0, b0 == 0 ? e->clk_log : nullptr,
                                        e->rope_cos, e->rope_sin, e->cur_cos + (size_t)b0 * (D / 2), e->cur_sin + (size_t)b0 * (D / 2),
-                                       D / 2, c.max_seq_len, M, sampled, (unsigned*)nullptr));
+                                       D / 2, c.max_seq_len, M, sampled));
     *launches += 2;
     return PGK_OK;
 }
@@ -2058,12 +1897,12 @@ static pgk_status decode_chunk_batched(Engine* e, int b0, int M, bool last, hipS
 // fragments with the activation block in LDS by DMA, SwiGLU sits in the gate_up epilogue, and the N = hidden projections
 // are split along K over 256 workgroups with the next RMSNorm summing their slabs (rmsnorm_f32_bf16_kernel, as in
 // pgk_engine_prefill).  Attention (per-sequence positions, new-token norm / RoPE / cache write) is the batch kernel.
-static pgk_status decode_chunk_packed(Engine* e, int b0, int M, bool last, hipStream_t st, int* launches) {
+static pgk_status decode_chunk_packed(Engine* e, int b0, int M, bool last, hipStream_t st, int* launches, bool short_ctx) {
     const auto& c = e->cfg;
     const int H = c.hidden_size, I = c.intermediate_size, D = c.head_dim, QD = c.num_heads * D, NQKV = e->qkv_dim();
     float* h = e->h + (size_t)b0 * H;
     bf16* x16 = e->x16 + (size_t)b0 * H;
-    const bool direct = e->attn_direct_ok && M >= 3;
+    const bool direct = short_ctx && M >= 3;
     const int s_o = pkgemm_pick_splits(M, H, QD), s_d = pkgemm_pick_splits(M, H, I);
     int pending = 0;
     auto norm = [&](const bf16* gamma) -> pgk_status {
@@ -2086,8 +1925,8 @@ static pgk_status decode_chunk_packed(Engine* e, int b0, int M, bool last, hipSt
         else if (pgk_status r = norm((const bf16*)L.attn_norm)) return r;
         if (pgk_status r = pkgemm_nt(x16, H, P.qkv, e->qkv + (size_t)b0 * NQKV, NQKV, PK_EPI_SLAB, 1, M, NQKV, H, &nrm, st)) return r;
         mark(KC_ATTN);
-        if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, false, st, true)) return r; }
-        else { if (pgk_status r = launch_attn<64>(e, l, b0, M, false, st, true)) return r; }
+        if (D == 128) { if (pgk_status r = launch_attn<128>(e, l, b0, M, false, direct, st, true)) return r; }
+        else { if (pgk_status r = launch_attn<64>(e, l, b0, M, false, direct, st, true)) return r; }
         mark(KC_OPROJ);
         bf16* attn16 = e->attnv16 + (size_t)b0 * QD;
         if (!direct) {   // long contexts: the merge kernel leaves fp32 rows
@@ -2104,7 +1943,7 @@ static pgk_status decode_chunk_packed(Engine* e, int b0, int M, bool last, hipSt
             mark(KC_DOWN);
             const bf16* gnext = l + 1 < c.num_layers ? (const bf16*)e->layers[l + 1].attn_norm : nullptr;
             if (pgk_status r = pkgemm_resid_nt(act16, I, P.down, h, M, H, I, gnext, x16, e->pk_ss, &ss_n, st)) return r;
-            *launches += ((direct || e->merge_cnt) ? 5 : 6) + (l == 0 ? 1 : 0) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;
+            *launches += (direct ? 5 : 6) + (l == 0 ? 1 : 0) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;
             continue;
         }
         if (pgk_status r = pkgemm_nt(attn16, QD, P.o, e->dec_slabs, H, PK_EPI_SLAB, s_o, M, H, QD, nullptr, st)) return r;
@@ -2115,7 +1954,7 @@ static pgk_status decode_chunk_packed(Engine* e, int b0, int M, bool last, hipSt
         mark(KC_DOWN);
         if (pgk_status r = pkgemm_nt(act16, I, P.down, e->dec_slabs, H, PK_EPI_SLAB, s_d, M, H, I, nullptr, st)) return r;
         pending = s_d;
-        *launches += ((direct || e->merge_cnt) ? 7 : 8) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;
+        *launches += (direct ? 7 : 8) + gqa_chunks(c.num_heads / c.num_kv_heads) - 1;
     }
     const int nblk = ceil_div(c.vocab_size, 16) < 2048 ? ceil_div(c.vocab_size, 16) : 2048;
     if (pgk_status r = norm(e->final_norm)) return r;     // also folds the last down_proj's slabs into the residual stream
@@ -2140,15 +1979,16 @@ static pgk_status decode_chunk_packed(Engine* e, int b0, int M, bool last, hipSt
     PGK_CHECK_HIP(launch_k(finalize_kernel, dim3(M), dim3(256), 0, st, a.amax_val, a.amax_idx, nblk, e->tokens + b0, e->positions + b0, e->token_log + b0, e->step_counter,
                                        e->cfg.max_batch, e->log_cap, e->embed, h, H, last ? 1 : 0, b0 == 0 ? e->clk_log : nullptr,
                                        e->rope_cos, e->rope_sin, e->cur_cos + (size_t)b0 * (D / 2), e->cur_sin + (size_t)b0 * (D / 2),
-                                       D / 2, c.max_seq_len, M, sampled, (unsigned*)nullptr));
+                                       D / 2, c.max_seq_len, M, sampled));
     *launches += 3;
     return PGK_OK;
 }
 
+constexpr int SHORT_CTX = 512;   // contexts up to here take the whole-context attention kernels (fused o_proj / direct batch attention)
+
 template <class WT>
-static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* launches, hipStream_t st2) {
+static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* launches, bool short_ctx) {
     int b0 = 0;
-    const bool dual = e->dual_ok && batch == 1;      // one sequence on the fused path
     while (b0 < batch) {
         const int rem = batch - b0;
         pgk_status r;
@@ -2158,23 +1998,39 @@ static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* la
         const bool mfma_ok = e->batched_mfma && (rem >= e->batched_min || (e->batched_min == 5 && rem == 3));
         if (mfma_ok) {
             const int m = rem > e->batched_max ? e->batched_max : rem;
-            if (m > 16 && e->packed_decode && !std::is_same<WT, fp8e4m3>::value) r = decode_chunk_packed(e, b0, m, rem == m, st, launches);
-            else r = decode_chunk_batched<WT>(e, b0, m, rem == m, st, launches);
+            if (m > 16 && e->packed_decode && !std::is_same<WT, fp8e4m3>::value) r = decode_chunk_packed(e, b0, m, rem == m, st, launches, short_ctx);
+            else r = decode_chunk_batched<WT>(e, b0, m, rem == m, st, launches, short_ctx);
             b0 += m;
         }
-        else if (rem >= 8) { r = decode_chunk<WT, bf16, 8>(e, b0, rem == 8, st, launches); b0 += 8; }
-        else if (rem >= 4) { r = decode_chunk<WT, bf16, 4>(e, b0, rem == 4, st, launches); b0 += 4; }
-        else if (rem >= 2) { r = decode_chunk<WT, float, 2>(e, b0, rem == 2, st, launches); b0 += 2; }
-        else { r = decode_chunk<WT, float, 1>(e, b0, true, st, launches, dual && batch == 1, st2); b0 += 1; }
+        else if (rem >= 8) { r = decode_chunk<WT, bf16, 8>(e, b0, rem == 8, st, launches, short_ctx); b0 += 8; }
+        else if (rem >= 4) { r = decode_chunk<WT, bf16, 4>(e, b0, rem == 4, st, launches, short_ctx); b0 += 4; }
+        else if (rem >= 2) { r = decode_chunk<WT, float, 2>(e, b0, rem == 2, st, launches, short_ctx); b0 += 2; }
+        else { r = decode_chunk<WT, float, 1>(e, b0, true, st, launches, short_ctx); b0 += 1; }
         if (r != PGK_OK) return r;
     }
     return PGK_OK;
 }
 
-// st2: second capture branch for the dual chain (null / == st: everything on st)
-static pgk_status decode_step(Engine* e, int batch, hipStream_t st, int* launches, hipStream_t st2 = nullptr) {
-    if (e->cfg.weight_format != 0) return decode_step_impl<fp8e4m3>(e, batch, st, launches, st2);
-    return decode_step_impl<bf16>(e, batch, st, launches, st2);
+// short_ctx: the step's launch sequence for contexts <= SHORT_CTX (ignored - long sequence - when the engine has no such path)
+static pgk_status decode_step(Engine* e, int batch, hipStream_t st, int* launches, bool short_ctx) {
+    short_ctx = short_ctx && e->short_path;
+    if (e->cfg.weight_format != 0) return decode_step_impl<fp8e4m3>(e, batch, st, launches, short_ctx);
+    return decode_step_impl<bf16>(e, batch, st, launches, short_ctx);
+}
+
+// Which launch sequence the NEXT step takes: the short-context one while the host-side bound on the step's largest
+// position (set by pgk_engine_set_state, advanced by every step this library enqueues) stays below SHORT_CTX.  The bound
+// is a speed hint only - both sequences are correct at any context - so a caller that rewrites the device-resident
+// positions behind the library's back loses speed, never correctness; an unknown bound selects the long sequence.
+static bool step_is_short(const Engine* e) { return e->short_path && e->pos_hi >= 0 && e->pos_hi + 1 <= SHORT_CTX; }
+
+static void drop_graphs(Engine* e) {
+    for (int i = 0; i < 2; ++i) {
+        if (e->exec[i]) { (void)hipGraphExecDestroy(e->exec[i]); e->exec[i] = nullptr; }
+        if (e->graph[i]) { (void)hipGraphDestroy(e->graph[i]); e->graph[i] = nullptr; }
+        e->graph_launches[i] = 0;
+    }
+    e->graph_batch = 0;
 }
 
 }  // namespace pgk
@@ -2207,7 +2063,6 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             e->cu_count = prop.multiProcessorCount;
-        if (const char* ew = getenv("PGK_ATTN_WAVES")) e->attn_waves = atoi(ew) > 0 ? atoi(ew) : 0;
     }
     e->nsplit = nsplit < 1 ? 1 : (nsplit > 64 ? 64 : nsplit);
     e->lm_blocks = 1024;
@@ -2218,16 +2073,14 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         while (rows > 4 * rpp && rows % 2 == 0) rows /= 2;   // <= 4 preloaded passes per workgroup
         while (rows < rpp) rows *= 2;
         const bool tiles = rows % rpp == 0 && c.hidden_size % rows == 0 && gd / 8 <= 64;
-#ifdef PGK_ABLATION
-        if (const char* dbg = getenv("PGK_DEBUG_SKIP")) e->skip_attn = atoi(dbg) & 16;
-#endif
+        // PGK_FUSED_ATTN=0: no short-context launch sequence at all (the split-KV sequence at every context; A/B and tests)
         const char* env = getenv("PGK_FUSED_ATTN");
-        const bool want = env ? atoi(env) != 0 : true;
-        e->fused_attn = want && tiles && c.weight_format == 0 && c.max_seq_len <= 512 && (G == 1 || G == 2 || G == 4);
+        e->short_path = env ? atoi(env) != 0 : true;
+        e->fused_attn = tiles && c.weight_format == 0 && (G == 1 || G == 2 || G == 4);
         e->oproj_rows = rows;
         {
             const char* am = getenv("PGK_ATTN_MFMA");
-            e->attn_mfma = e->fused_attn && c.head_dim == 128 && !(am && atoi(am) == 0);
+            e->attn_mfma = c.head_dim == 128 && !(am && atoi(am) == 0);
         }
         // merged o_proj (long contexts, fp8 W_o): same slicing rule with 16 codes per lane for fp8
         const int nwt = c.weight_format != 0 ? 16 : 8, lpw = gd / nwt, rpp2 = lpw > 0 ? 256 / lpw : 256;
@@ -2268,13 +2121,7 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
     e->lm_cap = e->lm_blocks > ceil_div(c.vocab_size, 16) ? e->lm_blocks : ceil_div(c.vocab_size, 16);   // per-sequence argmax partial slots
     {
         const char* ev = getenv("PGK_BATCHED_MFMA");
-        e->batched_min = (ev && atoi(ev) == 2) ? 3 : ((ev && atoi(ev) == 3) ? 9 : 5);   // 2: from 3 up; 3: the old threshold of 9
-        const char* ed = getenv("PGK_ATTN_DIRECT");
-        e->attn_direct_ok = c.max_seq_len <= 512 && !(ed && atoi(ed) == 0);
-        {
-            const char* amd = getenv("PGK_ATTN_MFMA_DIRECT");
-            e->attn_mfma_direct = e->attn_direct_ok && c.head_dim == 128 && !(amd && atoi(amd) == 0);
-        }
+        e->batched_min = (ev && atoi(ev) == 2) ? 3 : 5;   // 2: from 3 up
         // every projection's K must suit the MFMA decode kernels: K = 128 S with S in {8, 16, 24, 32} (activation
         // fragments in registers) or an LDS image of K x 16 bf16 that fits (K <= 4096); Llama-3-8B's down_proj
         // (K = 14336) does neither, so such models decode batches in GEMV chunks of 8 / 4 / 2 / 1
@@ -2283,46 +2130,11 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         // 17..64 sequences in one weight pass (batched_mt_kernel) need K = 128 S with S instantiated; otherwise chunks of 16
         auto k_tiled = [](int K) { const int s = K / 128; return K % 128 == 0 && (s == 2 || s == 4 || s == 8 || s == 16 || s == 24 || s == 32); };
         e->batched_max = (k_tiled(c.hidden_size) && k_tiled(c.intermediate_size) && k_tiled(c.num_heads * c.head_dim)) ? 64 : 16;
-        if (const char* tn = getenv("PGK_TILED_NORM_FUSED")) e->tiled_norm_fused = atoi(tn) != 0;
         if (const char* em = getenv("PGK_BATCHED_MAX")) { const int v = atoi(em); if (v >= 16 && v < e->batched_max) e->batched_max = v; }
-    }
-    {
-        // Off by default: measured at context 2048 the release/acquire hand-off costs more than the kernel boundary it
-        // replaces (attention phase 13.9 us vs 11.4 us with the separate 4.7 us merge kernel; 1118 vs 1240 tok/s).
-        const char* em = getenv("PGK_ATTN_INKERNEL_MERGE");
-        if (em && atoi(em) == 1 && (G == 1 || G == 2 || G == 4)) {
-            A((void**)&e->merge_cnt, (size_t)B * c.num_kv_heads * 4, &e->ws_bytes);
-            if (e->merge_cnt) PGK_CHECK_HIP(hipMemset(e->merge_cnt, 0, (size_t)B * c.num_kv_heads * 4));
-        }
     }
     A((void**)&e->amax_val, (size_t)B * e->lm_cap * 4, &e->ws_bytes);
     A((void**)&e->amax_idx, (size_t)B * e->lm_cap * 4, &e->ws_bytes);
     A((void**)&e->clk_log, (size_t)e->log_cap * 16, &e->ws_bytes);
-    {
-        // dual-chain step: counters for the 4 L layer kernels + epoch + error word, one allocation, zeroed once
-        const size_t words = (size_t)4 * c.num_layers * DEP_SHARDS * DEP_STRIDE + 2 * DEP_STRIDE;
-        A((void**)&e->dep_cnt, words * 4, &e->ws_bytes);
-        if (r == PGK_OK) {
-            e->dep_epoch = e->dep_cnt + (size_t)4 * c.num_layers * DEP_SHARDS * DEP_STRIDE;
-            e->dep_err = e->dep_epoch + DEP_STRIDE;
-            if (hipMemset(e->dep_cnt, 0, words * 4) != hipSuccess) r = set_error(PGK_ERR_HIP, "pgk_engine_create: hipMemset of the dual-chain counters failed");
-        }
-        // every GEMV of the fused step must take its compile-time-K instance (the one that preloads its weights and
-        // knows how to wait): K = 512 C with C in {1,2,3,4,6} and C x rows-per-wave <= 8
-        auto c_ok = [](int K, int R) { const int cc = K / 512; return K % 512 == 0 && (cc == 1 || cc == 2 || cc == 3 || cc == 4 || cc == 6) && cc * R <= 8; };
-        const int nq = e->qkv_dim();
-        const int r_qkv = nq >= 4096 ? 4 : (nq >= 2048 ? 2 : 1), r_gu = 4;
-        const int r_dn = c.hidden_size >= 4096 ? 4 : (c.hidden_size >= 2048 ? 2 : 1);
-        if (const char* g4 = getenv("PGK_GATEUP_R4")) e->gateup_r4 = atoi(g4) == 1;
-        const char* ed = getenv("PGK_DUAL_CHAIN");
-        e->dual_ok = (ed && atoi(ed) == 1) && e->fused_attn && c.weight_format == 0 && c_ok(c.hidden_size, r_qkv) && c_ok(c.hidden_size, r_gu) &&
-                     c_ok(c.intermediate_size, r_dn);
-        if (e->dual_ok && r == PGK_OK) {
-            if (hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess)
-                e->dual_ok = false;
-        }
-    }
     {
         // Second, fragment-major copy of the bf16 layer weights: what the short-prompt prefill streams (ops_pkgemm.hip).
         // Costs the layers' bytes again; skipped when that is more than a quarter of the device's free memory.
@@ -2349,13 +2161,11 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
             }
             if (r == PGK_OK && hipStreamSynchronize(st) != hipSuccess) r = set_error(PGK_ERR_HIP, "pgk_engine_create: packing the prefill weights failed");
             e->packed_ok = r == PGK_OK;
-            const char* pr = getenv("PGK_PACKED_RESID");
-            if (e->packed_ok && pkgemm_resid_ok(H, QDp) && pkgemm_resid_ok(H, I) && !(pr && atoi(pr) == 0)) {
+            if (e->packed_ok && pkgemm_resid_ok(H, QDp) && pkgemm_resid_ok(H, I)) {
                 A((void**)&e->pk_ss, (size_t)128 * PK_SS_LD * 4, &e->ws_bytes);
                 e->packed_resid = r == PGK_OK;
             }
-            const char* pl = getenv("PGK_PACKED_LMHEAD");
-            if (e->packed_ok && c.max_batch >= 3 && c.vocab_size % 16 == 0 && H % 32 == 0 && !(pl && atoi(pl) == 0)) {
+            if (e->packed_ok && c.max_batch >= 3 && c.vocab_size % 16 == 0 && H % 32 == 0) {
                 A((void**)&e->packed_lm, (size_t)c.vocab_size * H * 2, &e->packed_bytes);
                 if (r == PGK_OK) r = pack_weights_bf16(e->lm_head, e->packed_lm, c.vocab_size, H, st);
                 if (r == PGK_OK && hipStreamSynchronize(st) != hipSuccess) r = set_error(PGK_ERR_HIP, "pgk_engine_create: packing the lm_head failed");
@@ -2400,11 +2210,7 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
 pgk_status pgk_engine_destroy(pgk_engine eh) {
     if (!eh) return PGK_OK;
     Engine* e = (Engine*)eh;
-    if (e->exec) (void)hipGraphExecDestroy(e->exec);
-    if (e->graph) (void)hipGraphDestroy(e->graph);
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    if (e->st2) (void)hipStreamDestroy(e->st2);
+    drop_graphs(e);
     for (void* p : e->allocs) (void)pgk_free(p);
     if (e->pf) (void)pgk_free(e->pf);
     if (e->pf_tokens) (void)pgk_free(e->pf_tokens);
@@ -2435,11 +2241,8 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     // 129..256 tokens on the packed-weight path: two chunks of <= 128 through its kernels (5 launches per layer, the second
     // chunk attending to the first through the cache) beat one pass through the generic GEMMs (9 launches per layer)
     if (n > 128 && n <= 256 && e->packed_ok && all_logits == nullptr) {
-        static const bool chunk_off = [] { const char* ev = getenv("PGK_PREFILL_CHUNKS"); return ev && atoi(ev) == 0; }();
-        if (!chunk_off) {
-            if (pgk_status r = pgk_engine_prefill(eh, seq, h_tokens, 128, start_pos, nullptr, nullptr, s)) return r;
-            return pgk_engine_prefill(eh, seq, h_tokens + 128, n - 128, start_pos + 128, nullptr, h_last_logits, s);
-        }
+        if (pgk_status r = pgk_engine_prefill(eh, seq, h_tokens, 128, start_pos, nullptr, nullptr, s)) return r;
+        return pgk_engine_prefill(eh, seq, h_tokens + 128, n - 128, start_pos + 128, nullptr, h_last_logits, s);
     }
     const int H = c.hidden_size, I = c.intermediate_size, D = c.head_dim, QD = c.num_heads * D, NQKV = e->qkv_dim();
     // workspace: h32 [n,H] f32 | x [n,H] | qkv [n,NQKV] | attn [n,QD] | gu [n,2I] | act [n,I]  (bf16)
@@ -2640,6 +2443,8 @@ pgk_status pgk_engine_set_state(pgk_engine eh, const int32_t* h_tokens, const in
                     h_positions[b], e->cfg.max_seq_len);
     }
     hipStream_t st = resolve_stream(s);
+    e->pos_hi = 0;
+    for (int b = 0; b < batch; ++b) e->pos_hi = h_positions[b] > e->pos_hi ? h_positions[b] : e->pos_hi;
     PGK_CHECK_HIP(hipMemcpyAsync(e->tokens, h_tokens, (size_t)batch * 4, hipMemcpyHostToDevice, st));
     PGK_CHECK_HIP(hipMemcpyAsync(e->positions, h_positions, (size_t)batch * 4, hipMemcpyHostToDevice, st));
     // the residual stream enters a step already holding the embeddings of the state tokens
@@ -2655,8 +2460,9 @@ pgk_status pgk_engine_decode_step(pgk_engine eh, int batch, pgk_stream s) {
     Engine* e = (Engine*)eh;
     PGK_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch, "pgk_engine_decode_step: batch %d outside [1,%d]", batch, e->cfg.max_batch);
     int launches = 0;
-    pgk_status r = decode_step(e, batch, resolve_stream(s), &launches);
+    pgk_status r = decode_step(e, batch, resolve_stream(s), &launches, step_is_short(e));
     e->launches_per_step = launches;
+    if (e->pos_hi >= 0) ++e->pos_hi;
     return r;
 }
 
@@ -2677,8 +2483,9 @@ pgk_status pgk_engine_profile_step(pgk_engine eh, int batch, int n_iters, float*
         probe.info.clear();
         g_probe = &probe;
         int launches = 0;
-        r = decode_step(e, batch, st, &launches);
+        r = decode_step(e, batch, st, &launches, step_is_short(e));
         g_probe = nullptr;
+        if (e->pos_hi >= 0) ++e->pos_hi;
         if (r != PGK_OK) break;
         hipError_t he = hipStreamSynchronize(st);
         if (he != hipSuccess) { r = set_error(PGK_ERR_HIP, "pgk_engine_profile_step: %s", hipGetErrorString(he)); break; }
@@ -2719,12 +2526,13 @@ pgk_status pgk_engine_timeline(pgk_engine eh, int batch, int warm, uint64_t* h_o
     if (he == hipSuccess) {
         g_probe = &probe;
         int launches = 0;
-        r = decode_step(e, batch, st, &launches, e->dual_ok ? e->st2 : nullptr);
+        r = decode_step(e, batch, st, &launches, step_is_short(e));
         g_probe = nullptr;
         he = hipStreamEndCapture(st, &g);
     }
     if (r == PGK_OK && he == hipSuccess) he = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
     for (int i = 0; r == PGK_OK && he == hipSuccess && i <= warm; ++i) he = hipGraphLaunch(ex, st);
+    if (e->pos_hi >= 0) e->pos_hi += warm + 1;
     if (r == PGK_OK && he == hipSuccess) he = hipStreamSynchronize(st);
     const int n = (int)probe.info.size() < cap ? (int)probe.info.size() : cap;
     if (r == PGK_OK && he == hipSuccess) {
@@ -2785,28 +2593,41 @@ pgk_status pgk_engine_capture(pgk_engine eh, int batch, pgk_stream s) {
     Engine* e = (Engine*)eh;
     PGK_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch, "pgk_engine_capture: batch %d outside [1,%d]", batch, e->cfg.max_batch);
     hipStream_t st = resolve_stream(s);
-    if (e->exec) { (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
-    if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
-    PGK_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-    int launches = 0;
-    pgk_status r = decode_step(e, batch, st, &launches, e->dual_ok ? e->st2 : nullptr);
-    hipGraph_t g = nullptr;
-    hipError_t he = hipStreamEndCapture(st, &g);
-    if (r != PGK_OK) { if (g) (void)hipGraphDestroy(g); return r; }
-    if (he != hipSuccess || !g) return set_error(PGK_ERR_HIP, "pgk_engine_capture: hipStreamEndCapture: %s", hipGetErrorString(he));
-    e->graph = g;
-    PGK_CHECK_HIP(hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0));
+    drop_graphs(e);
+    // [0]: the split-KV sequence, needed whenever a context can exceed SHORT_CTX (or the short sequences are switched off);
+    // [1]: the short-context sequence.  pgk_engine_replay picks per step.
+    const bool want[2] = {!e->short_path || e->cfg.max_seq_len > SHORT_CTX, e->short_path};
+    for (int v = 0; v < 2; ++v) {
+        if (!want[v]) continue;
+        PGK_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        int launches = 0;
+        pgk_status r = decode_step(e, batch, st, &launches, v == 1);
+        hipGraph_t g = nullptr;
+        hipError_t he = hipStreamEndCapture(st, &g);
+        if (r != PGK_OK) { if (g) (void)hipGraphDestroy(g); drop_graphs(e); return r; }
+        if (he != hipSuccess || !g) { drop_graphs(e); return set_error(PGK_ERR_HIP, "pgk_engine_capture: hipStreamEndCapture: %s", hipGetErrorString(he)); }
+        e->graph[v] = g;
+        he = hipGraphInstantiate(&e->exec[v], g, nullptr, nullptr, 0);
+        if (he != hipSuccess) { drop_graphs(e); return set_error(PGK_ERR_HIP, "pgk_engine_capture: hipGraphInstantiate: %s", hipGetErrorString(he)); }
+        e->graph_launches[v] = launches;
+    }
     e->graph_batch = batch;
-    e->launches_per_step = launches;
+    e->launches_per_step = e->graph_launches[step_is_short(e) ? 1 : 0];
     return PGK_OK;
 }
 
 pgk_status pgk_engine_replay(pgk_engine eh, int n_steps, pgk_stream s) {
     PGK_REQUIRE(eh, "pgk_engine_replay: null engine");
     Engine* e = (Engine*)eh;
-    PGK_REQUIRE(e->exec, "pgk_engine_replay: no captured graph (call pgk_engine_capture first)");
+    PGK_REQUIRE(e->exec[0] || e->exec[1], "pgk_engine_replay: no captured graph (call pgk_engine_capture first)");
     hipStream_t st = resolve_stream(s);
-    for (int i = 0; i < n_steps; ++i) PGK_CHECK_HIP(hipGraphLaunch(e->exec, st));
+    for (int i = 0; i < n_steps; ++i) {
+        int v = (step_is_short(e) && e->exec[1]) ? 1 : 0;
+        if (!e->exec[v]) v = 1 - v;        // only one sequence was captured (short caches; PGK_FUSED_ATTN=0)
+        PGK_CHECK_HIP(hipGraphLaunch(e->exec[v], st));
+        e->launches_per_step = e->graph_launches[v];
+        if (e->pos_hi >= 0) ++e->pos_hi;
+    }
     return PGK_OK;
 }
 
@@ -2824,14 +2645,8 @@ pgk_status pgk_engine_read_tokens(pgk_engine eh, int32_t* h_out, int batch, int 
     hipStream_t st = resolve_stream(s);
     // log rows are max_batch wide; return the first `batch` columns, step-major
     std::vector<int32_t> tmp((size_t)n_steps * e->cfg.max_batch);
-    unsigned dep_err = 0;
-    PGK_CHECK_HIP(hipMemcpyAsync(&dep_err, e->dep_err, 4, hipMemcpyDeviceToHost, st));
     if (n_steps) PGK_CHECK_HIP(hipMemcpyAsync(tmp.data(), e->token_log, tmp.size() * 4, hipMemcpyDeviceToHost, st));
     PGK_CHECK_HIP(hipStreamSynchronize(st));
-    if (dep_err) {
-        (void)hipMemsetAsync(e->dep_err, 0, 4, st);
-        return set_error(PGK_ERR_HIP, "pgk_engine_read_tokens: a dual-chain wait timed out during the last steps (tokens invalid); set PGK_DUAL_CHAIN=0");
-    }
     for (int t = 0; t < n_steps; ++t)
         for (int b = 0; b < batch; ++b) h_out[(size_t)t * batch + b] = tmp[(size_t)t * e->cfg.max_batch + b];
     return PGK_OK;
@@ -2862,9 +2677,8 @@ pgk_status pgk_engine_set_sampling(pgk_engine eh, float temperature, int top_k, 
     Engine* e = (Engine*)eh;
     hipStream_t st = resolve_stream(s);
     auto drop_graph = [&]() {
-        if (e->exec) { (void)hipStreamSynchronize(st); (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
-        if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
-        e->graph_batch = 0;
+        if (e->exec[0] || e->exec[1]) (void)hipStreamSynchronize(st);
+        drop_graphs(e);
     };
     if (temperature <= 0.f) {
         if (e->sample_temperature > 0.f) drop_graph();          // a captured sampling node must not be replayed as "greedy"
@@ -2903,26 +2717,6 @@ pgk_status pgk_engine_set_sampling(pgk_engine eh, float temperature, int top_k, 
     e->sample_temperature = temperature;
     e->sample_top_k = top_k;
     e->sample_top_p = top_p;
-    return PGK_OK;
-}
-
-// Diagnostic: dual-chain state after a device sync: h_out[0] = epoch, [1] = error word, [2 + k] = arrivals of layer kernel k
-// (k < 4 L, summed over the shards).
-pgk_status pgk_engine_dep_state(pgk_engine eh, uint32_t* h_out, int n) {
-    PGK_REQUIRE(eh && h_out, "pgk_engine_dep_state: null argument");
-    Engine* e = (Engine*)eh;
-    const int nk = 4 * e->cfg.num_layers;
-    PGK_REQUIRE(n >= nk + 2, "pgk_engine_dep_state: need %d words", nk + 2);
-    std::vector<uint32_t> host((size_t)nk * DEP_SHARDS * DEP_STRIDE + 2 * DEP_STRIDE);
-    PGK_CHECK_HIP(hipDeviceSynchronize());
-    PGK_CHECK_HIP(hipMemcpy(host.data(), e->dep_cnt, host.size() * 4, hipMemcpyDeviceToHost));
-    h_out[0] = host[(size_t)nk * DEP_SHARDS * DEP_STRIDE];
-    h_out[1] = host[(size_t)nk * DEP_SHARDS * DEP_STRIDE + DEP_STRIDE];
-    for (int k = 0; k < nk; ++k) {
-        uint32_t sum = 0;
-        for (int sh = 0; sh < DEP_SHARDS; ++sh) sum += host[((size_t)k * DEP_SHARDS + sh) * DEP_STRIDE];
-        h_out[2 + k] = sum;
-    }
     return PGK_OK;
 }
 

@@ -16,7 +16,7 @@
 // MP: activation rows held in LDS (8 or 16).  S: 32-k steps per wave preloaded into registers (K = 128 S when it is one of
 // the instantiated 8 / 16 / 24; any further steps stream through a plain loop).
 template <class WT, int PRO, int EPI, int MP, int S>
-__global__ __launch_bounds__(256) void batched_mfma_kernel(FusedArgs a, int M, int steps /* K / 128 per wave */, int nblk_logits, unsigned long long* tl) {
+__global__ __launch_bounds__(256) void batched_mfma_kernel(unsigned long long* tl, FusedArgs a, int M, int steps /* K / 128 per wave */, int nblk_logits) {
     const TLStamp tls(tl);
     constexpr bool FP8 = std::is_same<WT, fp8e4m3>::value;
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;       // weight row groups per workgroup
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void batched_mfma_kernel(FusedArgs a, int M, i
 // and the epilogue ignores those columns (the MFMA computes them on whatever the registers hold - columns are
 // independent).
 template <class WT, int PRO, int EPI, int S, int RPG>
-__global__ __launch_bounds__(256) void batched_reg_kernel(FusedArgs a, int M, int nblk_logits, unsigned long long* tl) {
+__global__ __launch_bounds__(256) void batched_reg_kernel(unsigned long long* tl, FusedArgs a, int M, int nblk_logits) {
     const TLStamp tls(tl);
     constexpr bool FP8 = std::is_same<WT, fp8e4m3>::value;
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
@@ -443,10 +443,9 @@ __global__ __launch_bounds__(256) void batched_reg_kernel(FusedArgs a, int M, in
 // group an lm_head workgroup walks); beyond that they stream from L2 in chunks of CH = 4 k-steps, the next chunk's loads
 // issued before the current chunk's MFMAs.  Rows >= M of the last tile repeat row M - 1: MFMA output rows are independent
 // and the epilogue drops them.
-constexpr int SS_LD = 1024;     // row stride of the per-workgroup sum-of-squares table [64][SS_LD] (producers launch <= 1024 workgroups)
 
 template <class WT, int EPI, int S, int RPG, int MT>
-__global__ __launch_bounds__(256) void batched_mt_kernel(FusedArgs a, int M, int nblk_logits, unsigned long long* tl) {
+__global__ __launch_bounds__(256) void batched_mt_kernel(unsigned long long* tl, FusedArgs a, int M, int nblk_logits) {
     const TLStamp tls(tl);
     constexpr bool FP8 = std::is_same<WT, fp8e4m3>::value;
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
@@ -454,7 +453,6 @@ __global__ __launch_bounds__(256) void batched_mt_kernel(FusedArgs a, int M, int
     constexpr int NCH = S / CH;
     static_assert(S % CH == 0, "chunking");
     __shared__ float red[NT * 4 * MT * 256];               // [NT][4 waves][MT][16 m][16 n]
-    __shared__ float s_inv[64];                            // per-row 1 / rms when the rows arrive un-normalised (ss_in)
     const int K = a.K, N = a.N;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, q = lane >> 4, l15 = lane & 15;
     const int ngroups = (N + RPG - 1) / RPG;
@@ -494,31 +492,6 @@ __global__ __launch_bounds__(256) void batched_mt_kernel(FusedArgs a, int M, int
             }
         }
     };
-    if (a.ss_in) {
-        // row statistic from the producer's per-workgroup partial sums, [64 rows][SS_LD] with a row's partials contiguous: a
-        // wave takes 16 rows, one 16-byte load per lane and row (all 16 in flight), fixed summation order (deterministic).
-        // Done FIRST: vector memory returns in issue order, so behind the weight loads these L2 words would only arrive with
-        // the last HBM byte, and with their 64 registers live next to the activation fragments the kernel drops to one
-        // wave per SIMD (both measured slower than a norm launch); used only in the epilogue, behind the barriers below
-        float4 pv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c0 = 0; c0 < a.ss_n; c0 += 256) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = c0 + 4 * lane;
-                const float4 v = *reinterpret_cast<const float4*>(a.ss_in + (size_t)(wid * 16 + r) * SS_LD + min(c, SS_LD - 4));
-                pv[r].x += c < a.ss_n ? v.x : 0.f; pv[r].y += c + 1 < a.ss_n ? v.y : 0.f;
-                pv[r].z += c + 2 < a.ss_n ? v.z : 0.f; pv[r].w += c + 3 < a.ss_n ? v.w : 0.f;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float tot = wave_sum((pv[r].x + pv[r].y) + (pv[r].z + pv[r].w));
-            if (lane == 0) s_inv[wid * 16 + r] = 1.0f / sqrtf(tot / K + a.eps);
-        }
-    }
-
     __builtin_amdgcn_sched_barrier(0);
     load_w(blockIdx.x * RPG);                              // in flight before the activations are touched
     const int em = tid >> 4, en = tid & 15;
@@ -595,11 +568,10 @@ __global__ __launch_bounds__(256) void batched_mt_kernel(FusedArgs a, int M, int
             const int m = t * 16 + em;
             const bool ok = m < M && en < RPG && n0 + en < N;
             float y[NT];
-            const float rs = a.ss_in ? s_inv[min(m, 63)] : 1.0f;
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
                 const float* p = red + ((size_t)(u * 4) * MT + t) * 256 + em * 16 + en;
-                y[u] = ok ? (p[0] + p[MT * 256] + p[2 * MT * 256] + p[3 * MT * 256]) * rs : 0.f;
+                y[u] = ok ? (p[0] + p[MT * 256] + p[2 * MT * 256] + p[3 * MT * 256]) : 0.f;
             }
             const size_t o = (size_t)m * a.ld_out + n0 + en;
             if constexpr (EPI == EPI_STORE) {
@@ -607,11 +579,6 @@ __global__ __launch_bounds__(256) void batched_mt_kernel(FusedArgs a, int M, int
             } else if constexpr (EPI == EPI_RESID) {
                 const float v = resv[t] + y[0];
                 if (ok) a.out[o] = v;
-                if (a.hb16_out) {          // next RMSNorm's input (un-normalised, gamma applied) + this workgroup's share of its statistic
-                    if (ok) a.hb16_out[o] = from_f<bf16>(v * to_f(a.gamma_next[min(n0 + en, N - 1)]));
-                    const float sq = group16_sum(ok ? v * v : 0.f);       // the 16 lanes of a row: columns n0 .. n0 + 15
-                    if (en == 0 && m < M && (int)blockIdx.x < SS_LD) a.ss_out[(size_t)m * SS_LD + blockIdx.x] = sq;
-                }
             } else if constexpr (EPI == EPI_SWIGLU) {
                 if (ok) {
                     const float act = y[0] / (1.0f + __expf(-y[0])) * y[NT - 1];
@@ -656,7 +623,6 @@ static int mt_rows_per_group(int N, int epi) { return (epi == EPI_LOGITS || ceil
 template <class WT, int EPI, int S>
 static pgk_status launch_batched_mt(const FusedArgs& a, int M, hipStream_t st, int nblk_logits) {
     const int rpg = mt_rows_per_group(a.N, EPI);
-    PGK_REQUIRE(!(a.ss_out && ceil_div(a.N, rpg) > SS_LD) && !(a.ss_in && a.ss_n > SS_LD), "batched decode projection: sum-of-squares table holds %d workgroups", SS_LD);
     const int grid = (EPI == EPI_LOGITS) ? nblk_logits : ceil_div(a.N, rpg);
     const bool two = M <= 32;
     hipError_t he = hipSuccess;
@@ -692,7 +658,6 @@ template <class WT, int PRO, int EPI, int S>
 static pgk_status launch_batched_reg(const FusedArgs& a, int M, hipStream_t st, int nblk_logits) {
     // enough workgroups to pull HBM bandwidth: fewer weight rows per workgroup when N / 16 would leave CUs idle
     int rpg = (EPI == EPI_LOGITS || ceil_div(a.N, 16) >= 192) ? 16 : (ceil_div(a.N, 8) >= 192 ? 8 : 4);
-    if (const char* e = getenv("PGK_BATCHED_RPG")) { const int v = atoi(e); if (EPI != EPI_LOGITS && rpg != 16 && (v == 4 || v == 8 || v == 16)) rpg = v; }
     const int grid = (EPI == EPI_LOGITS) ? nblk_logits : ceil_div(a.N, rpg);
     hipError_t he;
     if (rpg == 16) he = launch_k(batched_reg_kernel<WT, PRO, EPI, S, 16>, dim3(grid), dim3(256), 0, st, a, M, nblk_logits);
@@ -718,15 +683,11 @@ template <class WT, int PRO, int EPI>
 static pgk_status launch_batched(const FusedArgs& a, int M, hipStream_t st, int nblk_logits = 0) {
     PGK_REQUIRE(a.K % 128 == 0 && M >= 1 && M <= 16, "batched decode projection: K=%d must be a multiple of 128 and M=%d in [1,16]", a.K, M);
     const int steps = a.K / 128, ngroups = ceil_div(a.N, 16);
-    {   // register-resident activations (PGK_BATCHED_REG=0: the LDS-image kernel below, for A/B runs)
-        const char* re = getenv("PGK_BATCHED_REG");
-        if (!(re && atoi(re) == 0)) {
-            if (steps == 8) return launch_batched_reg<WT, PRO, EPI, 8>(a, M, st, nblk_logits);
-            if (steps == 16) return launch_batched_reg<WT, PRO, EPI, 16>(a, M, st, nblk_logits);
-            if (steps == 24) return launch_batched_reg<WT, PRO, EPI, 24>(a, M, st, nblk_logits);
-            if (steps == 32) return launch_batched_reg<WT, PRO, EPI, 32>(a, M, st, nblk_logits);
-        }
-    }
+    // register-resident activations at the instantiated widths; the LDS-image kernel below for every other K
+    if (steps == 8) return launch_batched_reg<WT, PRO, EPI, 8>(a, M, st, nblk_logits);
+    if (steps == 16) return launch_batched_reg<WT, PRO, EPI, 16>(a, M, st, nblk_logits);
+    if (steps == 24) return launch_batched_reg<WT, PRO, EPI, 24>(a, M, st, nblk_logits);
+    if (steps == 32) return launch_batched_reg<WT, PRO, EPI, 32>(a, M, st, nblk_logits);
     // the prologue (RMSNorm of the M rows) is per workgroup: large N (lm_head) runs 2048 workgroups over several groups each
     const int grid = (EPI == EPI_LOGITS) ? nblk_logits : ngroups;
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;

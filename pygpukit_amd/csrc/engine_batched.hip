@@ -14,7 +14,7 @@ typedef float f32x4_b __attribute__((ext_vector_type(4)));
 
 // x16[m][:] = bf16(h[m][:] * rsqrt(mean(h[m]^2) + eps) * gamma)   (gamma == nullptr: plain fp32 -> bf16 rows)
 // One 256-thread workgroup per row; rows up to 4096 columns stay in registers between the two passes.
-__global__ __launch_bounds__(256) void norm_rows_bf16_kernel(const float* h, const bf16* gamma, bf16* out, int K, float eps, unsigned long long* tl) {
+__global__ __launch_bounds__(256) void norm_rows_bf16_kernel(unsigned long long* tl, const float* h, const bf16* gamma, bf16* out, int K, float eps) {
     const TLStamp tls(tl);
     __shared__ float red[16];
     const float* hr = h + (size_t)blockIdx.x * K;
@@ -61,7 +61,6 @@ __global__ __launch_bounds__(256) void norm_rows_bf16_kernel(const float* h, con
     tls.end();
 }
 
-int batched_tiled_groups(int N, int epi) { return ceil_div(N, mt_rows_per_group(N, epi)); }
 
 pgk_status norm_rows_bf16(const float* h, const bf16* gamma, bf16* x16, int M, int K, float eps, hipStream_t st) {
     PGK_REQUIRE(h && x16 && M >= 1 && K >= 4 && K % 4 == 0, "norm_rows_bf16: bad arguments (M=%d, K=%d)", M, K);

@@ -425,12 +425,6 @@ static bool flash_decoding_off() {
     return e && atoi(e) == 0 && strcmp(e, "auto") != 0;
 }
 
-// 0 = first-generation kernel only, 1 = second-generation (ops_flash.hip) whenever it applies; default: by size
-static int flash_gen_choice() {
-    static const int v = [] { const char* e = getenv("PGK_FLASH_GEN"); return e ? atoi(e) : -1; }();
-    return v;
-}
-
 template <class T>
 static pgk_status sdpa_dispatch(const void* q, const void* k, const void* v, void* out, int hq, int hkv, int q_len,
                                 int kv_len, int d, float scale, const AttnStrides& sd, hipStream_t st) {
@@ -440,14 +434,12 @@ static pgk_status sdpa_dispatch(const void* q, const void* k, const void* v, voi
         // second generation: 128-row query tiles, transposed-score orientation (ops_flash.hip); the first-generation
         // kernel keeps the short prompts, where its 64-row tiles give twice the workgroups
         const bool gen2_ok = mfma_ok && (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && sd.os % 4 == 0 && sd.oh % 4 == 0;
-        const int gen = flash_gen_choice();
-        if (gen2_ok && (gen == 1 || (gen < 0 && q_len > 128)))
+        if (gen2_ok && q_len > 128)
             return flash_prefill(q, k, v, out, hq, hkv, q_len, kv_len, d, scale, sd.qh, sd.qs, sd.kh, sd.ks, sd.oh, sd.os,
                                  std::is_same<T, f16>::value ? 1 : 0, st);
         if constexpr (std::is_same<T, bf16>::value) {
-            // the whole context in one tile (attn_short_kernel); PGK_ATTN_SHORT=0 keeps the flash kernel
-            static const bool short_off = [] { const char* e = getenv("PGK_ATTN_SHORT"); return e && atoi(e) == 0; }();
-            if (gen2_ok && !short_off && d == 128 && kv_len <= 128 && gen < 0) {
+            // the whole context in one tile (attn_short_kernel)
+            if (gen2_ok && d == 128 && kv_len <= 128) {
                 attn_short_kernel<2><<<dim3(ceil_div(q_len, 32), hq), 128, 0, st>>>((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, hq, hkv,
                                                                                   q_len, kv_len, scale, sd);
                 PGK_CHECK_HIP(hipGetLastError());

@@ -209,17 +209,14 @@ __global__ __launch_bounds__(256) void quantize_blocks_kernel(const bf16* w, uin
 
 pgk_status gemm256_fp8_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, void* c, bool accum_f32, int M, int N,
                           int K, hipStream_t st);
+bool want_gemm256(int M, int N);      // ops_gemm.hip
 
 // internal entry used by the engine's fp8-activation prefill
 pgk_status gemm_fp8_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, void* c, bool accum_f32, int M,
                        int N, int K, hipStream_t st) {
     PGK_REQUIRE(M >= 1 && N >= 1 && K >= 128 && K % 128 == 0, "gemm_fp8: K=%d must be a positive multiple of 128 (M=%d N=%d)", K, M, N);
-    {   // enough 256 x 256 tiles to fill the chip: the LDS-DMA structure (ops_gemm256.hip)
-        const char* e = getenv("PGK_GEMM256");
-        const int force = e ? atoi(e) : -1;
-        if (force == 1 || (force < 0 && (long long)ceil_div(M, 256) * ceil_div(N, 256) >= 192))
-            return gemm256_fp8_nt(a, sa, w, sw, c, accum_f32, M, N, K, st);
-    }
+    // enough 256 x 256 tiles to fill the chip: the LDS-DMA structure (ops_gemm256.hip)
+    if (want_gemm256(M, N)) return gemm256_fp8_nt(a, sa, w, sw, c, accum_f32, M, N, K, st);
     constexpr size_t LDS = 4 * (size_t)F8_TILE + 2 * F8_BM * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {

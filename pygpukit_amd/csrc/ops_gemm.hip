@@ -22,13 +22,16 @@ pgk_status wsgemm_nt(const bf16* a, int lda, const void* w, const bf16* wscale, 
 pgk_status gemm256_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, bool accum_f32, int M, int N, int K,
                            hipStream_t st);
 // the 256 x 256 structure needs enough tiles to fill the chip and whole 128-byte K rows
-static bool use_gemm256(int M, int N, int K) {
-    const char* e = getenv("PGK_GEMM256");   // read per call: tests flip it to drive small shapes through both kernels
+// PGK_GEMM256 = 0 / 1 forces the choice (read per call: tests flip it to drive small shapes through both kernels); shared
+// with the fp8 x fp8 GEMM (ops_fp8_gemm.hip)
+bool want_gemm256(int M, int N) {
+    const char* e = getenv("PGK_GEMM256");
     const int force = e ? atoi(e) : -1;
-    if (force == 0 || K % 64 != 0) return false;
+    if (force == 0) return false;
     if (force == 1) return true;
     return (long long)ceil_div(M, 256) * ceil_div(N, 256) >= 192;
 }
+static bool use_gemm256(int M, int N, int K) { return K % 64 == 0 && want_gemm256(M, N); }
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -347,10 +350,6 @@ static pgk_status dispatch_mfma(const T* A, const void* B, const bf16* bscale, c
     // 128 x 64 tiles that only just cover the chip (one 4-wave workgroup per CU, nothing to overlap its barriers with)
     // lose to twice as many 64 x 64 tiles: M=2048, N=1024, K=2048/3072 measured 23.9 / 33.9 us against 28.3 / 39.9
     if (bm == 128 && bn == 64 && mblocks * ((N + 63) / 64) < 512) { bm = 64; mblocks = (M + 63) / 64; }
-    if (const char* e = getenv("PGK_GEMM_TILE")) {   // experiments: "bm,bn"
-        int a_ = 0, b_ = 0;
-        if (sscanf(e, "%d,%d", &a_, &b_) == 2) { bm = a_; bn = b_; }
-    }
     if (MODE == B_KN_FP8 && bn < 64) bn = 64;  // keep whole 16-code chunks per thread
 #define PGK_TILE(BM_, BN_) if (bm == BM_ && bn == BN_) return launch_mfma<T, BM_, BN_, MODE, EPI>(A, B, bscale, bias, C, M, N, K, st);
     PGK_TILE(128, 128) PGK_TILE(128, 64) PGK_TILE(128, 32)
@@ -385,9 +384,8 @@ __global__ __launch_bounds__(256) void dequant_fp8_blocks_kernel(const uint8_t* 
 // N = 1024: 128 tiles; the 64 x 64 tiles that do cover it run at 200-290 TFLOP/s) - the 128-tile kernel split along K into
 // `splits` fp32 slabs [splits][M][N] that the next RMSNorm sums.  Returns the number of slabs through the argument; 1 = not used.
 int engine_gemm_pick_splits(int M, int N, int K) {
-    static const bool off = [] { const char* e = getenv("PGK_GEMM_SPLITK"); return e && atoi(e) == 0; }();   // A/B switch
     const long long tiles = (long long)ceil_div(M, 128) * ceil_div(N, 128);
-    if (off || M <= 128 || tiles >= 192 || use_gemm256(M, N, K)) return 1;
+    if (M <= 128 || tiles >= 192 || use_gemm256(M, N, K)) return 1;
     int s = (int)(256 / tiles);
     if (s > 4) s = 4;
     while (s > 1 && K / s < 512) --s;

@@ -611,9 +611,7 @@ pgk_status pkgemm_nt(const bf16* a, int lda, const void* wp, void* c, int ldc, i
     // 16-row m-blocks (twice the workgroups, fewer bytes each) while they still fit one round at one workgroup per CU, and
     // always up to 96 rows; else 32-row blocks, which re-read the weights half as often (measured at 128 rows: QKV 256 x 16-row
     // workgroups instead of 128 x 32-row ones pays, gate_up with 384 does not)
-    static const int mt_force = [] { const char* e = getenv("PGK_PK_MT"); return e ? atoi(e) : 0; }();
-    int mt = (M <= 96 || g.nblk * splits * ceil_div(M, 16) <= 256) ? 1 : 2;
-    if (mt_force == 1 || mt_force == 2) mt = mt_force;
+    const int mt = (M <= 96 || g.nblk * splits * ceil_div(M, 16) <= 256) ? 1 : 2;
     g.mblk = ceil_div(M, 16 * mt);
     const size_t lds = (size_t)16 * mt * g.ksteps * 64;
     PGK_REQUIRE(lds <= 128 * 1024, "pkgemm: K per workgroup %d too long for the LDS activation block", g.ksteps * 32);

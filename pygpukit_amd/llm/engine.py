@@ -139,13 +139,6 @@ class Engine:
                         "first_start_us": s0 / 100.0, "last_start_us": s1 / 100.0, "first_end_us": e0 / 100.0, "last_end_us": e1 / 100.0})
         return out
 
-    def dep_state(self) -> dict:
-        """Dual-chain diagnostics: steps completed, timeout flag, arrivals per layer kernel (device sync first)."""
-        n = 4 * self.config["num_layers"] + 2
-        buf = (C.c_uint32 * n)()
-        _hip.call("pgk_engine_dep_state", self.handle, buf, n)
-        return {"epoch": int(buf[0]), "timed_out": bool(buf[1]), "arrivals": [int(buf[2 + k]) for k in range(n - 2)]}
-
     def capture(self, batch: int = 1) -> None:
         _hip.call("pgk_engine_capture", self.handle, batch, None)
         self._captured_batch = batch

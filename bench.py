@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: BASELINE.json metric "decode tokens/sec/GPU + prefill TFLOPS, Qwen3-0.6B bf16".
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: one process per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment - what
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` sets, or any other launcher; nothing here imports torch)
 
 Headline (`value`) at every N = BASELINE config 2 per GPU: random-init Qwen3-0.6B-shape bf16 weights, a 128-token
 prompt prefilled through the MFMA path, then K single-token greedy decode steps, each ONE replay of the whole-step
@@ -20,7 +22,8 @@ Extra objects on the JSON line:
   roofline         the decode-step kernel with the largest share of the step's device time: algorithmic bytes per
                    launch / its average dispatch duration (start/stop events on every launch of eager steps on the
                    launch stream: the begin -> end interval rocprofv3 --kernel-trace reports), vs 8 TB/s HBM;
-                   `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc pass named in `traffic_source`.
+                   `traffic` = HBM bytes per launch, only when THIS run is itself a rocprofv3 --pmc pass whose counters a
+                   later reduction fills in (null otherwise; the round's measured values are in profiles/README.md).
   roofline_kernels the same row for every kernel of the step (per-launch us, bytes, frac, share of the step).
   step_roofline    whole decode step: algorithmic bytes per token / measured step time.
   prefill          ms, TFLOP/s and fraction of the 2.5 PFLOP/s dense bf16 MFMA peak for the 128-token prompt.
@@ -42,7 +45,6 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
-PMC_FILE = "profiles/r02_decode_pmc_hbm.json"
 
 
 def algorithmic_bytes_per_token(cfg: dict, ctx: int, weight_format: str) -> dict:
@@ -122,6 +124,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch-per-gpu", type=int, default=1, help="sequences per GPU of the HEADLINE leg (BASELINE config 2: 1)")
     ap.add_argument("--prompt-len", type=int, default=128)
+    ap.add_argument("--max-seq-len", type=int, default=0,
+                    help="KV-cache rows per sequence of the headline engine (default: prompt + warmup + steps + 8); the launch "
+                         "sequence follows the CONTEXT, not this capacity")
     ap.add_argument("--weight-format", choices=["bf16", "fp8"], default="bf16")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-decode-tokens", type=int, default=16)
@@ -141,6 +146,7 @@ def main() -> None:
     from pygpukit_amd.core.factory import from_numpy
     from pygpukit_amd.llm import synthetic as S
     from pygpukit_amd.llm.engine import Engine
+    from pygpukit_amd import parallel as DP
     from pygpukit_amd.parallel import ControlPlane, RcclComm
 
     cp = ControlPlane()
@@ -150,32 +156,58 @@ def main() -> None:
     _hip.call("pgk_device_set", cp.local_rank % max(ndev, 1))
     # RCCL carries the one-time weight broadcast and the end-of-run token gather.  For N > 1 it is mandatory: a run
     # whose communicator does not come up prints the reason and exits non-zero instead of reporting a number that no
-    # RCCL traffic stands behind.  (Every rank takes the same branch: the control-plane collectives stay matched.)
-    comm = None
-    if cp.world > 1:
-        note, ok = None, 1
-        if cp.local_rank >= ndev:
-            ok, note = 0, f"rank {cp.rank}: LOCAL_RANK {cp.local_rank} has no GPU of its own ({ndev} visible)"
-        all_have_gpu = cp.min_over_ranks(ok) > 0
-        if all_have_gpu:
-            try:
-                comm = RcclComm(cp)
-            except Exception as e:  # noqa: BLE001
-                ok, note = 0, f"rank {cp.rank}: {type(e).__name__}: {e}"
-        if cp.min_over_ranks(ok) == 0:
-            note = cp.first_note(note)
-            if cp.rank == 0:
-                print(json.dumps({"error": "RCCL is mandatory for --gpus > 1 and did not come up", "detail": note, "n_gpus": cp.world}))
-            if comm is not None:
-                comm.destroy()
-            cp.shutdown()
-            raise SystemExit(3)
+    # RCCL traffic stands behind (parallel.open_comm: every rank takes the same branch).
+    try:
+        comm = DP.open_comm(cp, ndev, RcclComm)
+    except DP.CommUnavailable as e:
+        if cp.rank == 0:
+            print(json.dumps({"error": "RCCL is mandatory for --gpus > 1 and did not come up", "detail": str(e), "n_gpus": cp.world}))
+        cp.shutdown()
+        raise SystemExit(3)
+
+    start_ev, stop_ev = _hip.C.c_void_p(), _hip.C.c_void_p()
+    _hip.call("pgk_event_create", _hip.C.byref(start_ev))
+    _hip.call("pgk_event_create", _hip.C.byref(stop_ev))
+
+    class GpuOps:
+        """parallel.py's `ops` protocol on the device: GPUArrays, hipEvents on the default stream."""
+        @staticmethod
+        def sync():
+            _hip.call("pgk_device_sync")
+
+        @staticmethod
+        def empty(shape, dt):
+            return GPUArray(tuple(shape), {np.dtype(np.int32): int32}[np.dtype(dt)])
+
+        from_host = staticmethod(from_numpy)
+
+        @staticmethod
+        def to_host(arr):
+            return arr.to_numpy()
+
+        @staticmethod
+        def nbytes(arr):
+            return arr.nbytes
+
+        @staticmethod
+        def timer_start():
+            _hip.call("pgk_event_record", start_ev, None)
+
+        @staticmethod
+        def timer_stop_ms():
+            _hip.call("pgk_event_record", stop_ev, None)
+            _hip.call("pgk_event_sync", stop_ev)
+            ms = _hip.C.c_float()
+            _hip.call("pgk_event_elapsed_ms", start_ev, stop_ev, _hip.C.byref(ms))
+            return ms.value
+
+    ops = GpuOps()
 
     cfg = dict(S.QWEN3_0_6B)
     if args.layers:
         cfg["num_layers"] = args.layers
     B, K, W, P = args.batch_per_gpu, args.steps, args.warmup, args.prompt_len
-    max_seq = P + W + K + 8
+    max_seq = max(args.max_seq_len, P + W + K + 8)
     t_setup = time.perf_counter()
 
     # ---- weights on the device: rank 0 draws them, every other rank receives them over RCCL (xGMI broadcast) ----
@@ -196,18 +228,7 @@ def main() -> None:
     else:
         embed, fnorm = GPUArray((V, H), bfloat16), GPUArray((H,), bfloat16)
         layers = [{k: GPUArray(s, dt) for k, (s, dt) in shapes.items()} for _ in range(cfg["num_layers"])]
-    bcast = None
-    if comm is not None:
-        _hip.call("pgk_device_sync")
-        cp.barrier()
-        t0 = time.perf_counter()
-        nbytes = 0
-        for arr in [embed, fnorm] + [lw[k] for lw in layers for k in shapes]:
-            comm.broadcast(arr, 0)
-            nbytes += arr.nbytes
-        _hip.call("pgk_device_sync")
-        dt = cp.max_over_ranks(time.perf_counter() - t0)
-        bcast = {"seconds": dt, "GB": nbytes / 1e9, "GBps": nbytes / 1e9 / dt, "via": "rccl broadcast, rank 0 -> all"}
+    bcast = DP.broadcast_weights(cp, comm, [embed, fnorm] + [lw[k] for lw in layers for k in shapes], ops)
 
     def new_engine(max_seq_len, max_batch):
         return Engine(cfg, embed, layers, fnorm, None, max_seq_len=max_seq_len, max_batch=max_batch, weight_format=args.weight_format)
@@ -220,10 +241,6 @@ def main() -> None:
     mine = all_prompts[cp.rank * B:(cp.rank + 1) * B]
 
     # ---- prefill (MFMA path), timed on sequence slot 0 ----
-    start_ev, stop_ev = _hip.C.c_void_p(), _hip.C.c_void_p()
-    _hip.call("pgk_event_create", _hip.C.byref(start_ev))
-    _hip.call("pgk_event_create", _hip.C.byref(stop_ev))
-
     def timed_ms(fn, reps):
         out = []
         for _ in range(reps):
@@ -236,59 +253,20 @@ def main() -> None:
             out.append(ms.value)
         return out
 
-    first = np.zeros(B, np.int32)
-    for b in range(B):
-        first[b] = int(np.argmax(eng.prefill([int(t) for t in mine[b]], seq=b)))
-    pf_ms = timed_ms(lambda: eng.prefill([int(t) for t in mine[0]], seq=0, want_last_logits=False), 5)
+    # ---- headline: whole-step hipGraph, state in device memory; every rank's token log gathered once after the timed steps ----
+    head = DP.headline_leg(cp, comm, eng, mine, ops, batch=B, prompt_len=P, warm=W, steps=K)
+    wall_max, dev_ms_max, tokens, gather = head["wall_s"], head["device_ms"], head["tokens"], head["gather"]
+    if gather is not None:
+        gather.pop("all_tokens")
+    pf_ms = timed_ms(lambda: eng.prefill([int(t) for t in mine[0]], seq=0, want_last_logits=False), 5)    # slot 0's rows are rewritten with the same values
     pf_med = float(np.median(pf_ms))
     pf_flops = prefill_flops(cfg, P, all_rows=False)
-
-    # ---- one decode leg: `batch` sequences on this GPU, `steps` timed graph replays between barrier + sync brackets ----
-    def decode_leg(e, batch, warm, steps):
-        e.capture(batch)
-        e.replay(warm)
-        _hip.call("pgk_device_sync")
-        cp.barrier()
-        _hip.call("pgk_device_sync")
-        t0 = time.perf_counter()
-        _hip.call("pgk_event_record", start_ev, None)
-        for _ in range(steps):
-            e.replay(1)   # one whole-step graph launch; no collective and no host sync inside a step
-        _hip.call("pgk_event_record", stop_ev, None)
-        _hip.call("pgk_device_sync")
-        cp.barrier()
-        wall = time.perf_counter() - t0
-        ms = _hip.C.c_float()
-        _hip.call("pgk_event_elapsed_ms", start_ev, stop_ev, _hip.C.byref(ms))
-        return cp.max_over_ranks(wall), cp.max_over_ranks(ms.value)
-
-    # ---- headline: whole-step hipGraph, state in device memory ----
-    eng.set_state(first, [P] * B)
-    wall_max, dev_ms_max = decode_leg(eng, B, W, K)
-    tokens = eng.read_tokens(B, min(W + K, 4096))
-    # the harness's view of the whole batch: every rank's token log gathered once, after the timed steps
-    gather = None
-    if comm is not None:
-        t0 = time.perf_counter()
-        mine_log = from_numpy(np.ascontiguousarray(tokens, dtype=np.int32))
-        all_log = GPUArray((cp.world,) + tuple(tokens.shape), int32)
-        comm.all_gather(mine_log, all_log)
-        _hip.call("pgk_device_sync")
-        all_tokens = all_log.to_numpy()
-        gather = {"seconds": time.perf_counter() - t0, "bytes_per_rank": int(tokens.nbytes), "via": "rccl all_gather",
-                  "own_shard_round_trips": bool(np.array_equal(all_tokens[cp.rank], tokens))}
-        gather["own_shard_round_trips"] = bool(cp.min_over_ranks(1.0 if gather["own_shard_round_trips"] else 0.0) > 0)
 
     # ---- per-kernel timing: eager steps, start/stop events on every launch (rank 0's numbers are reported) ----
     prof = eng.profile_step(B, 8)
     ctx_mid = P + W + K // 2
     ab = algorithmic_bytes_per_token(cfg, ctx_mid, args.weight_format)
     step_ms = dev_ms_max / K
-    pmc = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))
-    except Exception:
-        pass
     rows = []
     kb = kernel_bytes_per_launch(cfg, ctx_mid, B)
     NAMES = {"norm_qkv": "fused_gemv_kernel<PRO_NORM, EPI_STORE> (RMSNorm + qkv projection)",
@@ -307,9 +285,6 @@ def main() -> None:
                "share_of_step_kernel_time": us * n / total_us if total_us else None, "bound": "hbm",
                "bytes_per_launch": by, "achieved": by / us / 1e3 if (by and us) else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": by / us / 1e3 / HBM_PEAK_GBS if (by and us) else None, "traffic": None}
-        if pmc and k in pmc.get("kernels", {}) and B == 1 and args.weight_format == "bf16":
-            row["traffic"] = pmc["kernels"][k]["hbm_bytes_per_launch"]
-            row["traffic_source"] = PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on another box; reads x2 per the microarch guide)"
         rows.append(row)
     rows.sort(key=lambda r: -(r["share_of_step_kernel_time"] or 0))
     roofline = dict(rows[0]) if rows else None
@@ -325,28 +300,12 @@ def main() -> None:
     extras = None
     if not args.no_extras and B == 1 and args.weight_format == "bf16" and P == 128:
         extras = {}
-        # ---- BASELINE config 4 at this N: weak (8 per GPU) and strong (64 / N per GPU) ----
-        def config4_leg(b_local, tag):
-            steps, warm = args.config4_steps, 4
-            e4 = new_engine(P + steps + warm + 8, b_local)
-            pr = np.random.default_rng(3000 + args.seed).integers(0, cfg["vocab_size"], (cp.world * b_local, P))[cp.rank * b_local:(cp.rank + 1) * b_local]
-            f0 = [int(np.argmax(e4.prefill([int(t) for t in pr[b]], seq=b))) for b in range(b_local)]
-            e4.set_state(f0, [P] * b_local)
-            wall, dev_ms = decode_leg(e4, b_local, warm, steps)
-            ab4 = algorithmic_bytes_per_token(cfg, P + warm + steps // 2, "bf16")
-            by = ab4["weights"] + ab4["lm_head"] + b_local * (ab4["kv_read"] + ab4["kv_write"] + ab4["logits"])
-            out = {"scaling": tag, "batch_per_gpu": b_local, "global_batch": b_local * cp.world, "n_gpus": cp.world,
-                   "tokens_per_s": cp.world * b_local * steps / wall, "tokens_per_s_per_gpu": b_local * steps / wall,
-                   "ms_per_step": wall * 1e3 / steps, "device_ms_per_step": dev_ms / steps, "steps": steps, "context": P,
-                   "launches_per_step": e4.launches_per_step(), "hbm_frac_per_gpu": by / (dev_ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            del e4
-            return out
-        extras["config4"] = {"weak": config4_leg(8, "weak")}
-        if 64 % cp.world == 0:
-            extras["config4"]["strong"] = config4_leg(64 // cp.world, "strong")
-        extras["config4"]["note"] = ("BASELINE config 4: Qwen3-0.6B bf16 batch decode, data-parallel replicas, no collective inside a step; "
-                                     "scaling efficiency weak = tokens_per_s(N) / (N x tokens_per_s(1)), strong = tokens_per_s(N) / tokens_per_s(1) / N "
-                                     "against the N = 1 line's legs")
+        # ---- BASELINE config 4 at this N: weak (8 per GPU) and strong (64 / N per GPU); parallel.config4_legs ----
+        def bytes4(b_local):
+            ab4 = algorithmic_bytes_per_token(cfg, P + 4 + args.config4_steps // 2, "bf16")
+            return ab4["weights"] + ab4["lm_head"] + b_local * (ab4["kv_read"] + ab4["kv_write"] + ab4["logits"])
+        extras["config4"] = DP.config4_legs(cp, new_engine, lambda n, plen: np.random.default_rng(3000 + args.seed).integers(0, cfg["vocab_size"], (n, plen)),
+                                            ops, prompt_len=P, steps=args.config4_steps, warm=4, bytes_per_step=bytes4, hbm_peak_gbs=HBM_PEAK_GBS)
 
     # ---- single-GPU-only legs ----
     long_pf = None
@@ -426,7 +385,7 @@ def main() -> None:
         "config": {"workload": f"Qwen3-0.6B-shape random-init {args.weight_format}, prefill {P} + {K}-token greedy decode, "
                                f"whole-step hipGraph, {B} sequence(s) per GPU (BASELINE config 2{'' if cp.world == 1 else ' on every GPU: data-parallel replicas'})",
                    "batch_per_gpu": B, "global_batch": cp.world * B, "prompt_len": P, "parallelism": f"dp{cp.world}",
-                   "layers": cfg["num_layers"]},
+                   "layers": cfg["num_layers"], "max_seq_len": max_seq},
         "tokens_per_s_per_gpu": B * K / wall_max, "device_ms_per_step": step_ms,
         "roofline": roofline, "roofline_kernels": rows, "step_roofline": step_roofline,
         "prefill": {"ms": pf_med, "tflops": pf_flops / (pf_med * 1e-3) / 1e12, "flops": pf_flops, "logits": "last row only",

@@ -115,6 +115,26 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(unsigned long long* tl,
         constexpr int NP = (PRO == PRO_NORM_SUM) ? 8 : 1;
         const int np = (PRO == PRO_NORM_SUM) ? naux_ : 1;
         float hv[M][KJ], gv[NORM ? KJ : 1], pvs[PRO == PRO_NORM_SUM ? M : 1][PRO == PRO_NORM_SUM ? KJ : 1][NP];
+        // A thread owns KJ / VW runs of VW consecutive elements (run v starts at element (256 v + thread) * VW): every load of
+        // the prologue is one 16-byte (K % 1024 == 0) or 8-byte access per run - a quarter of the instructions of the
+        // element-per-load form, and the texture addresser moves 1 KiB instead of 256 B per wave-instruction.  The gate/up
+        // kernel reads nine such vectors (h + 8 o_proj partials) in every workgroup: more bytes through a CU's addresser
+        // than its share of the weights.
+        constexpr int VW = (KJ % 4 == 0) ? 4 : 2, NV = KJ / VW;
+        auto run0 = [&](int v) -> int { return (256 * v + (int)threadIdx.x) * VW; };
+        auto ldrun = [&](const float* base, int v, float* dst) {
+            if constexpr (VW == 4) { const float4 t = *reinterpret_cast<const float4*>(base + run0(v)); dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w; }
+            else { const float2 t = *reinterpret_cast<const float2*>(base + run0(v)); dst[0] = t.x; dst[1] = t.y; }
+        };
+        auto strun = [&](float* base, int v, const float* src) {
+            if constexpr (VW == 4) *reinterpret_cast<float4*>(base + run0(v)) = make_float4(src[0], src[1], src[2], src[3]);
+            else *reinterpret_cast<float2*>(base + run0(v)) = make_float2(src[0], src[1]);
+        };
+        auto stx = [&](int m, int v, const float* src) {        // the LDS image of row m
+            if constexpr (std::is_same<XT, float>::value) strun(reinterpret_cast<float*>(xs) + (size_t)m * KC, v, src);
+            else if constexpr (VW == 4) *reinterpret_cast<uint2*>(xs + (size_t)m * KC + run0(v)) = make_uint2(pack_bf16x2(src[0], src[1]), pack_bf16x2(src[2], src[3]));
+            else *reinterpret_cast<uint32_t*>(xs + (size_t)m * KC + run0(v)) = pack_bf16x2(src[0], src[1]);
+        };
         // ---- activation loads ----
         if constexpr (EPI == EPI_RESID) {
 #pragma unroll
@@ -124,27 +144,37 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(unsigned long long* tl,
         }
         if constexpr (NORM) {
 #pragma unroll
-            for (int j = 0; j < KJ; ++j) {
-                const int i = threadIdx.x + 256 * j;
-                gv[j] = to_f(gamma_[i]);
+            for (int v = 0; v < NV; ++v) {
+                if constexpr (VW == 4) {
+                    const uint2 g = *reinterpret_cast<const uint2*>(gamma_ + run0(v));
+                    gv[4 * v] = __uint_as_float(g.x << 16); gv[4 * v + 1] = __uint_as_float(g.x & 0xFFFF0000u);
+                    gv[4 * v + 2] = __uint_as_float(g.y << 16); gv[4 * v + 3] = __uint_as_float(g.y & 0xFFFF0000u);
+                } else {
+                    const uint32_t g = *reinterpret_cast<const uint32_t*>(gamma_ + run0(v));
+                    gv[2 * v] = __uint_as_float(g << 16); gv[2 * v + 1] = __uint_as_float(g & 0xFFFF0000u);
+                }
 #pragma unroll
-                for (int m = 0; m < M; ++m) hv[m][j] = *(x_ + (size_t)m * KC + i);
+                for (int m = 0; m < M; ++m) ldrun(x_ + (size_t)m * KC, v, &hv[m][VW * v]);
             }
             if constexpr (PRO == PRO_NORM_SUM) {
                 // partial vectors: unconditional clamped loads, masked adds below (one round trip for up to 8)
 #pragma unroll
                 for (int m = 0; m < M; ++m)
 #pragma unroll
-                    for (int j = 0; j < KJ; ++j)
+                    for (int p = 0; p < NP; ++p)
 #pragma unroll
-                        for (int p = 0; p < NP; ++p)
-                            pvs[m][j][p] = *(aux_ + ((size_t)m * np + min(p, np - 1)) * KC + threadIdx.x + 256 * j);
+                        for (int v = 0; v < NV; ++v) {
+                            float t[VW];
+                            ldrun(aux_ + ((size_t)m * np + min(p, np - 1)) * KC, v, t);
+#pragma unroll
+                            for (int e = 0; e < VW; ++e) pvs[m][VW * v + e][p] = t[e];
+                        }
             }
         } else if constexpr (PRO == PRO_PLAIN) {
 #pragma unroll
             for (int m = 0; m < M; ++m)
 #pragma unroll
-                for (int j = 0; j < KJ; ++j) hv[m][j] = *(x_ + (size_t)m * KC + threadIdx.x + 256 * j);
+                for (int v = 0; v < NV; ++v) ldrun(x_ + (size_t)m * KC, v, &hv[m][VW * v]);
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the compiler from hoisting the weight stream above the small loads
         load_weights();
@@ -164,7 +194,12 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(unsigned long long* tl,
 #pragma unroll
                     for (int m = 0; m < M; ++m)
 #pragma unroll
-                        for (int j = 0; j < KJ; ++j) hv[m][j] += *(aux_ + ((size_t)m * np + p) * KC + threadIdx.x + 256 * j);
+                        for (int v = 0; v < NV; ++v) {
+                            float t[VW];
+                            ldrun(aux_ + ((size_t)m * np + p) * KC, v, t);
+#pragma unroll
+                            for (int e = 0; e < VW; ++e) hv[m][VW * v + e] += t[e];
+                        }
             }
             float ss[M];
 #pragma unroll
@@ -184,17 +219,19 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(unsigned long long* tl,
                 const float tot = s_bv[0][m] + s_bv[1][m] + s_bv[2][m] + s_bv[3][m];
                 const float inv = 1.0f / sqrtf(tot / KC + a.eps);
 #pragma unroll
-                for (int j = 0; j < KJ; ++j) {
-                    const int i = threadIdx.x + 256 * j;
-                    if constexpr (PRO == PRO_NORM_SUM) { if (blockIdx.x == 0) *(a.h_out + (size_t)m * KC + i) = hv[m][j]; }
-                    store_x<XT>(xs, m * KC + i, hv[m][j] * inv * gv[j]);
+                for (int v = 0; v < NV; ++v) {
+                    if constexpr (PRO == PRO_NORM_SUM) { if (blockIdx.x == 0) strun(a.h_out + (size_t)m * KC, v, &hv[m][VW * v]); }
+                    float t[VW];
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) t[e] = hv[m][VW * v + e] * inv * gv[VW * v + e];
+                    stx(m, v, t);
                 }
             }
         } else if constexpr (PRO == PRO_PLAIN) {
 #pragma unroll
             for (int m = 0; m < M; ++m)
 #pragma unroll
-                for (int j = 0; j < KJ; ++j) store_x<XT>(xs, m * KC + threadIdx.x + 256 * j, hv[m][j]);
+                for (int v = 0; v < NV; ++v) stx(m, v, &hv[m][VW * v]);
         }
     }
     if constexpr (C == 0) {
@@ -1561,7 +1598,7 @@ template <class WT, class XT, int M, int R, int PRO, int EPI>
 static pgk_status launch_fused(const FusedArgs& a, int n_out, hipStream_t st, int force_grid = 0) {
     constexpr int NW = WTraits<WT>::NW;
     const int c = (a.K % (64 * NW) == 0) ? a.K / (64 * NW) : 0;
-    constexpr int BUDGET = 8 / R;  // R*C*4 preload VGPRs <= 32
+    constexpr int BUDGET = 12 / R;  // R*C*4 preload VGPRs <= 48
     if constexpr (1 <= BUDGET) { if (c == 1) return launch_fused_c<WT, XT, M, R, PRO, EPI, 1>(a, n_out, st, force_grid); }
     if constexpr (2 <= BUDGET) { if (c == 2) return launch_fused_c<WT, XT, M, R, PRO, EPI, 2>(a, n_out, st, force_grid); }
     if constexpr (3 <= BUDGET) { if (c == 3) return launch_fused_c<WT, XT, M, R, PRO, EPI, 3>(a, n_out, st, force_grid); }
@@ -1574,6 +1611,11 @@ static pgk_status launch_fused(const FusedArgs& a, int n_out, hipStream_t st, in
 template <class WT, class XT, int M, int PRO, int EPI>
 static pgk_status launch_fused_auto(const FusedArgs& a, int n_out, hipStream_t st) {
     if constexpr (EPI == EPI_SWIGLU) {
+        static const int tune_r = [] { const char* e = getenv("PGK_TUNE_GU_R"); return e ? atoi(e) : 0; }();   // TEMPORARY tuning knob
+        if constexpr (M == 1) {
+            if (tune_r == 6) return launch_fused<WT, XT, M, 6, PRO, EPI>(a, n_out, st);
+            if (tune_r == 4) return launch_fused<WT, XT, M, 4, PRO, EPI>(a, n_out, st);
+        }
         if (n_out >= 4096) return launch_fused<WT, XT, M, 4, PRO, EPI>(a, n_out, st);
         return launch_fused<WT, XT, M, 2, PRO, EPI>(a, n_out, st);
     } else {

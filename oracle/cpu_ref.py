@@ -464,6 +464,14 @@ def dequantize_fp8_e4m3_block(fp8_bytes: np.ndarray, scale_inv: np.ndarray,
     return r.reshape(H, W)
 
 
+def dequantize_fp8_e4m3_block_w8a16_gemm(fp8_bytes: np.ndarray, scale_inv: np.ndarray, block_size=(128, 128)) -> np.ndarray:
+    """[kernel-defined] native/ops/matmul/gemm/w8a16_bf16/sm120/w8a16_gemm.cu:187-203: the reference's w8a16 GEMM (every
+    M > 1 product of a LinearFP8: prefill and batched decode) dequantises each weight as lut[code] * scale in fp32 and
+    ROUNDS IT TO BF16 (`smB[...] = __float2bfloat16(dequant)`) before the bf16 MMA.  Its M = 1 GEMV
+    (gemv/w8a16_bf16/sm120/fp8_opt.cuh:62-122) keeps the fp32 product (gemv_fp8_bf16 below).  Returned widened to fp32."""
+    return bf16_round(dequantize_fp8_e4m3_block(fp8_bytes, scale_inv, block_size))
+
+
 def quantize_fp8_e4m3_block(w: np.ndarray, block_size=(128, 128)):
     """Synthetic-weight quantiser used by tests/bench:
     per 128x128 block scale = absmax/448 rounded to bf16, codes = nearest E4M3 value of

@@ -10,9 +10,9 @@
 // the end through LDS, and chunks are merged by a second tiny kernel (or by the consumer).
 #pragma once
 
-#include "pgk_device.cuh"
+#include "pgk_device.hip.h"
 
-// diagnostic builds (-DPGK_PHASE_STAMPS): stamps inside the walk, parked like TLStamp::phase (engine_common.cuh)
+// diagnostic builds (-DPGK_PHASE_STAMPS): stamps inside the walk, parked like TLStamp::phase (engine_common.hip.h)
 #ifdef PGK_PHASE_STAMPS
 static __device__ unsigned long long* g_phase_tl;
 #define PGK_PHASE(i)                                                                                              \

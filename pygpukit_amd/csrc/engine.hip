@@ -26,9 +26,9 @@
 #include <type_traits>
 #include <vector>
 
-#include "attn_core.cuh"
-#include "engine_common.cuh"
-#include "pkgemm.cuh"
+#include "attn_core.hip.h"
+#include "engine_common.hip.h"
+#include "pkgemm.hip.h"
 
 namespace pgk {
 
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(unsigned long long* tl
         KVBatch<U0> kb0;
         kv_issue<D, U0, 4>(kb0, a.kcache + head_off, a.vcache + head_off, wid * PPW, a.max_seq - 1, lane);
         __builtin_amdgcn_sched_barrier(0);
-        const int pos = load_uniform_i32(a.positions + b);   // scalar path (pgk_device.cuh): not queued behind the vector loads in flight
+        const int pos = load_uniform_i32(a.positions + b);   // scalar path (pgk_device.hip.h): not queued behind the vector loads in flight
         NewToken<D, G> t;
         new_token_finish<D, G>(a, lane, raw, t);
         if (pos < a.max_seq && wid == 0 && lane < LPR && a.g_off == 0) {
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(unsigned long long* tl
     KVBatch<U1> kb0;
     kv_issue<D, U1, 4>(kb0, a.kcache + head_off, a.vcache + head_off, c0 + wid * PPW, a.max_seq - 1, lane);
     __builtin_amdgcn_sched_barrier(0);
-    const int pos = load_uniform_i32(a.positions + b);   // scalar path (pgk_device.cuh): not queued behind the vector loads in flight
+    const int pos = load_uniform_i32(a.positions + b);   // scalar path (pgk_device.hip.h): not queued behind the vector loads in flight
     const int ctx = min(pos + 1, a.max_seq);
     tls.phase(0);
     NewToken<D, G> t;
@@ -1500,14 +1500,14 @@ __global__ void bf16_rows_to_f32_kernel(const bf16* in, float* out, size_t n) {
 }
 
 // --------------------------------------------------------------------------------------------
-thread_local Probe* g_probe = nullptr;   // measurement hooks: engine_common.cuh
+thread_local Probe* g_probe = nullptr;   // measurement hooks: engine_common.hip.h
 
 struct Engine {
     pgk_model_config_t cfg;
     const bf16 *embed, *lm_head, *final_norm;
     std::vector<pgk_layer_weights_t> layers;
     int nsplit = 1, lm_blocks = 1, lm_cap = 1, log_cap = 4096;
-    bool batched_mfma = true;   // chunks of 3 and 5..16 sequences use engine_batched.cuh (PGK_BATCHED_MFMA=0: GEMV kernels only, =2: from 3 up)
+    bool batched_mfma = true;   // chunks of 3 and 5..16 sequences use engine_batched.hip.h (PGK_BATCHED_MFMA=0: GEMV kernels only, =2: from 3 up)
     int batched_min = 5, batched_max = 64;   // PGK_BATCHED_MAX=16: chunks of at most 16 sequences (one weight pass per chunk), the A/B switch of the tiled kernels
     int cu_count = 256;
     bool short_path = true;     // contexts <= SHORT_CTX take the whole-context attention kernels (PGK_FUSED_ATTN=0: the split-KV sequence at every context)
@@ -1611,10 +1611,13 @@ static pgk_status launch_fused(const FusedArgs& a, int n_out, hipStream_t st, in
 template <class WT, class XT, int M, int PRO, int EPI>
 static pgk_status launch_fused_auto(const FusedArgs& a, int n_out, hipStream_t st) {
     if constexpr (EPI == EPI_SWIGLU) {
-        static const int tune_r = [] { const char* e = getenv("PGK_TUNE_GU_R"); return e ? atoi(e) : 0; }();   // TEMPORARY tuning knob
+        // One sequence, mid-sized gate/up (Qwen3-0.6B: 3072 pairs): 3 pairs per wave = 256 workgroups, one per CU.  Every
+        // workgroup's prologue re-reads h and the 8 o_proj partial vectors (36 KB from L2); with 768 two-pair workgroups that
+        // was 108 KB per CU through the texture addresser against 49 KB of weights (gate/up span 4.32 -> 3.69 us, step 0.607
+        // -> 0.592 ms; 4 pairs per wave = 384 workgroups: 4.28 us).  Needs the 6 rows x C chunks to fit the preload budget.
         if constexpr (M == 1) {
-            if (tune_r == 6) return launch_fused<WT, XT, M, 6, PRO, EPI>(a, n_out, st);
-            if (tune_r == 4) return launch_fused<WT, XT, M, 4, PRO, EPI>(a, n_out, st);
+            constexpr int NW = WTraits<WT>::NW;
+            if (n_out >= 2048 && n_out < 4096 && a.K % (64 * NW) == 0 && a.K / (64 * NW) <= 2) return launch_fused<WT, XT, M, 6, PRO, EPI>(a, n_out, st);
         }
         if (n_out >= 4096) return launch_fused<WT, XT, M, 4, PRO, EPI>(a, n_out, st);
         return launch_fused<WT, XT, M, 2, PRO, EPI>(a, n_out, st);

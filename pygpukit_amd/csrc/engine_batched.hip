@@ -1,16 +1,16 @@
-// Batched decode projections on MFMA (3..64 sequences per launch): kernels in engine_batched.cuh, run-time dispatch here.
+// Batched decode projections on MFMA (3..64 sequences per launch): kernels in engine_batched.hip.h, run-time dispatch here.
 // Its own translation unit so that the ~150 template instances compile beside engine.hip instead of inside it.
 
 #include <cstdlib>
 #include <type_traits>
 
-#include "engine_common.cuh"
+#include "engine_common.hip.h"
 
 namespace pgk {
 
 typedef __bf16 bf16x8_b __attribute__((ext_vector_type(8)));
 typedef float f32x4_b __attribute__((ext_vector_type(4)));
-#include "engine_batched.cuh"
+#include "engine_batched.hip.h"
 
 // x16[m][:] = bf16(h[m][:] * rsqrt(mean(h[m]^2) + eps) * gamma)   (gamma == nullptr: plain fp32 -> bf16 rows)
 // One 256-thread workgroup per row; rows up to 4096 columns stay in registers between the two passes.

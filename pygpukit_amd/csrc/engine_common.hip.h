@@ -7,7 +7,7 @@
 #include <tuple>
 #include <vector>
 
-#include "gemv_core.cuh"
+#include "gemv_core.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {

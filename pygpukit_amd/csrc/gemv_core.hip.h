@@ -17,7 +17,7 @@
 
 #include <type_traits>
 
-#include "pgk_device.cuh"
+#include "pgk_device.hip.h"
 
 namespace pgk {
 

@@ -12,7 +12,7 @@
 
 #include <cstring>
 
-#include "attn_core.cuh"
+#include "attn_core.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {

@@ -2,7 +2,7 @@
 // All HBM-bound: 16-byte accesses per lane, grid capped at 2048 blocks and grid-strided
 // (cdna_hip_programming.md Guideline 11/13).  fp32 math, one rounding on store.
 
-#include "pgk_device.cuh"
+#include "pgk_device.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {

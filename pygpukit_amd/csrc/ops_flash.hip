@@ -20,7 +20,7 @@
 
 #include <type_traits>
 
-#include "pgk_device.cuh"
+#include "pgk_device.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {
@@ -114,21 +114,37 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
     const int kr = tid / NC, kc16 = tid % NC;               // K: row kr + (256/NC) i, chunk kc16
     constexpr int KR_STEP = FL_THREADS / NC;
     const int vd = tid >> 3, vc = tid & 7;                  // V^T: row vd + 32 i, chunk vc
-    const T* vsrc = vh + (size_t)vd * kv_pad + vc * 8;
     auto k_src = [&](int kv0, int i) { return kh + (size_t)min(kv0 + kr + KR_STEP * i, kv_len - 1) * sd.ks + kc16 * 8; };
+    // Whole tiles address their rows as (wave-uniform tile base) + (per-lane element offset fixed for the kernel): the
+    // per-tile address arithmetic is scalar.  (Recomputing min(row, kv_len - 1) * stride per chunk cost 48 vector
+    // instructions per tile - 64-bit multiplies included - in a loop that is bound by vector issue.)  Only the ragged
+    // last tile clamps its rows.
+    const uint32_t ko0 = (uint32_t)(kr * sd.ks + kc16 * 8), ko_step = (uint32_t)(KR_STEP * sd.ks);
+    const uint32_t vo0 = (uint32_t)(vd * kv_pad + vc * 8), vo_step = (uint32_t)(32 * kv_pad);
     auto load_tile = [&](int t) {
         const int kv0 = t * FL_BKV;
-        rk0 = *reinterpret_cast<const uint4*>(k_src(kv0, 0));
-        rk1 = *reinterpret_cast<const uint4*>(k_src(kv0, 1));
-        if constexpr (KCH == 4) {
-            rk2 = *reinterpret_cast<const uint4*>(k_src(kv0, 2));
-            rk3 = *reinterpret_cast<const uint4*>(k_src(kv0, 3));
+        if (kv0 + FL_BKV <= kv_len) {      // wave-uniform
+            const T* kt = kh + (size_t)kv0 * sd.ks;
+            rk0 = *reinterpret_cast<const uint4*>(kt + ko0);
+            rk1 = *reinterpret_cast<const uint4*>(kt + ko0 + ko_step);
+            if constexpr (KCH == 4) {
+                rk2 = *reinterpret_cast<const uint4*>(kt + ko0 + 2 * ko_step);
+                rk3 = *reinterpret_cast<const uint4*>(kt + ko0 + 3 * ko_step);
+            }
+        } else {
+            rk0 = *reinterpret_cast<const uint4*>(k_src(kv0, 0));
+            rk1 = *reinterpret_cast<const uint4*>(k_src(kv0, 1));
+            if constexpr (KCH == 4) {
+                rk2 = *reinterpret_cast<const uint4*>(k_src(kv0, 2));
+                rk3 = *reinterpret_cast<const uint4*>(k_src(kv0, 3));
+            }
         }
-        rv0 = *reinterpret_cast<const uint4*>(vsrc + kv0);
-        rv1 = *reinterpret_cast<const uint4*>(vsrc + (size_t)32 * kv_pad + kv0);
+        const T* vtile = vh + kv0;
+        rv0 = *reinterpret_cast<const uint4*>(vtile + vo0);
+        rv1 = *reinterpret_cast<const uint4*>(vtile + vo0 + vo_step);
         if constexpr (VCH == 4) {
-            rv2 = *reinterpret_cast<const uint4*>(vsrc + (size_t)64 * kv_pad + kv0);
-            rv3 = *reinterpret_cast<const uint4*>(vsrc + (size_t)96 * kv_pad + kv0);
+            rv2 = *reinterpret_cast<const uint4*>(vtile + vo0 + 2 * vo_step);
+            rv3 = *reinterpret_cast<const uint4*>(vtile + vo0 + 3 * vo_step);
         }
     };
     auto put_v = [&](char* base, int d, const uint4& x) {
@@ -188,8 +204,10 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
                     s1[r] = 32 + kvl <= lim ? s1[r] : -INFINITY;
                 }
             }
+            // (this file is built with -fno-honor-nans: without it every operand of a max is first canonicalised with a
+            // v_max_f32 x, x, x of its own - 60 instructions for these 32 values instead of 16 v_max3_f32)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+            for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(fmaxf(s0[r], s1[r]), fmaxf(s0[r + 1], s1[r + 1])), mx);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             // Deferred rescale: the reference point of a row only moves when its maximum grew by more than 6 (log2
             // domain), so probabilities stay <= 64 (exact in fp32 sums, fine in 16-bit P) and on most tiles - for the whole
@@ -214,6 +232,16 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
                     for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
             }
             // ---- O^T += V^T . P^T : 4 k-steps of 16 kv ----
+            // V^T fragment addresses: row d = 32 i + ql, 8-byte chunk c8 = 4 s + 2 u + h at d * 128 + ((c8 ^ ((d >> 1) & 15)) << 3).
+            // 32 i is a multiple of 32, so the swizzle term depends on the lane and on c8 only: ONE address register per
+            // (s, u) for this tile's buffer and the tile row i as the instruction's immediate offset (4096 i).  The reads are
+            // VOLATILE: left ordinary, hipcc pairs those of tiles i and i + 2 into ds_read2st64_b64, which is served 16 lanes
+            // at a time on a 32-bank modulus (2-way conflicts, half the rate); the first version kept them apart by laundering
+            // every address through an empty asm - a v_mov + v_add per read, 64 vector instructions per tile.
+            typedef uint32_t fl_u32x2 __attribute__((ext_vector_type(2)));
+            typedef __attribute__((address_space(3))) const volatile fl_u32x2* fl_lds_cv64;     // volatile drops the inferred address space: say it
+            const char* vrow = Vs(buf) + ql * 128;
+            const int vsw = (ql >> 1) & 15;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 uint4 pb;
@@ -226,15 +254,9 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
                 }
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
-                    const int d = i * 32 + ql;
-                    // Each 8-byte read stays a ds_read_b64 (two 32-lane halves, 64-bank modulus - the layout above is
-                    // conflict-free for it).  Left visible, hipcc pairs the reads of tiles i and i+1 into ds_read2st64_b64,
-                    // which is served 16 lanes at a time on a 32-bank modulus: 2-way conflicts, half the rate.
-                    int off_lo = fl_v_off(d, 4 * s + h), off_hi = fl_v_off(d, 4 * s + 2 + h);
-                    asm volatile("" : "+v"(off_lo));
-                    asm volatile("" : "+v"(off_hi));
-                    const uint2 lo = *reinterpret_cast<const uint2*>(Vs(buf) + off_lo);
-                    const uint2 hi = *reinterpret_cast<const uint2*>(Vs(buf) + off_hi);
+                    // each 8-byte read stays a ds_read_b64 (two 32-lane halves, 64-bank modulus: the layout is conflict-free for it)
+                    const fl_u32x2 lo = *(fl_lds_cv64)(vrow + (((4 * s + h) ^ vsw) << 3) + i * 4096);
+                    const fl_u32x2 hi = *(fl_lds_cv64)(vrow + (((4 * s + 2 + h) ^ vsw) << 3) + i * 4096);
                     o[i] = mfma32<T>(make_uint4(lo.x, lo.y, hi.x, hi.y), pb, o[i]);
                 }
             }

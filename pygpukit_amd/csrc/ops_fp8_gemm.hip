@@ -17,7 +17,7 @@
 // The reference reaches CUTLASS for this (src/pygpukit/ops/matmul/fp8.py:270-343, native absent from the
 // checkout: parity for this op is pinned on the oracle's restatement of the formula above).
 
-#include "gemv_core.cuh"
+#include "gemv_core.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(F8_THREADS) void gemm_fp8_kernel(const uint8_t* A, 
 }
 
 // ---- quantisers --------------------------------------------------------------------------------
-// (pack_fp8x4: RNE f32 -> e4m3, pgk_device.cuh)
+// (pack_fp8x4: RNE f32 -> e4m3, pgk_device.hip.h)
 
 // Activations: one scale per row per 128 k.  16 lanes x 8 elements cover one (row, block); scale = absmax/448
 // (1 when the block is all zero), codes = RNE(x / scale).

@@ -11,7 +11,7 @@
 // The reference reaches for CUTLASS / cuBLASLt here (native/ops/matmul/matmul.cu:43-354); neither
 // exists on this target and nothing is linked in their place.
 
-#include "gemv_core.cuh"
+#include "gemv_core.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {

@@ -16,7 +16,7 @@
 //
 // The reference calls CUTLASS / cuBLASLt here (native/ops/matmul/matmul.cu:142-235); nothing of theirs is used.
 
-#include "gemv_core.cuh"
+#include "gemv_core.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {
@@ -38,6 +38,10 @@ __device__ __forceinline__ int g2_off(int r, int c) { return r * 128 + ((c ^ (r 
 // before the fragment reads are the explicit vmcnt + barrier pairs in the kernels below.
 __device__ __forceinline__ void g2_dma16(const void* src, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+}
+// the same with a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit byte offset
+__device__ __forceinline__ void g2_dma16_so(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
 __device__ __forceinline__ uint32_t g2_lds_addr(const char* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
@@ -292,14 +296,18 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
     const int m0 = tm * G2_BM, n0 = tn * G2_BN;
     const int KB = K >> 7, NB = (N + 127) >> 7;
 
+    // DMA sources as (uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset): 8 offset registers instead of 16
+    // pointer registers in a kernel that lives at the 256-register line, and the per-K-tile advance is one scalar add.
+    // Offsets are relative to the tile's first row (operand tiles span at most 255 rows x K <= 2^31 bytes).
     const int drow = wid * 32 + (lane >> 3);
     const int dchunk = (lane & 7) ^ (lane >> 3);
-    const uint8_t* a_src[4];
-    const uint8_t* w_src[4];
+    const uint8_t* a_tile = A + (size_t)m0 * K;
+    const uint8_t* w_tile = W + (size_t)n0 * K;
+    uint32_t a_off[4], w_off[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        a_src[i] = A + (size_t)min(m0 + drow + 8 * i, M - 1) * K + dchunk * 16;
-        w_src[i] = W + (size_t)min(n0 + drow + 8 * i, N - 1) * K + dchunk * 16;
+        a_off[i] = (uint32_t)(min(drow + 8 * i, M - 1 - m0) * K + dchunk * 16);
+        w_off[i] = (uint32_t)(min(drow + 8 * i, N - 1 - n0) * K + dchunk * 16);
     }
     // scale DMAs: waves 0-3 fetch 64 row scales each; wave 4 fetches the (up to) two weight-block scales
     const float* sa_src = sa + (size_t)min(m0 + (wid & 3) * 64 + lane, M - 1) * KB;
@@ -309,10 +317,12 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
         const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G2_TILE + wid * 4096);
         const uint32_t w_dst = __builtin_amdgcn_readfirstlane(lds0 + (2 + buf) * G2_TILE + wid * 4096);
         const uint32_t s_dst = __builtin_amdgcn_readfirstlane(lds0 + 4 * G2_TILE + buf * G2_SCALE_BYTES + (wid < 4 ? wid * 256 : 1024));
+        const uint8_t* ab = a_tile + (size_t)kt * 128;
+        const uint8_t* wb = w_tile + (size_t)kt * 128;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            g2_dma16(a_src[i] + (size_t)kt * 128, a_dst + i * 1024);
-            g2_dma16(w_src[i] + (size_t)kt * 128, w_dst + i * 1024);
+            g2_dma16_so(ab, a_off[i], a_dst + i * 1024);
+            g2_dma16_so(wb, w_off[i], w_dst + i * 1024);
         }
         if (wid < 4) g2_dma4(sa_src + kt, s_dst);
         else if (wid == 4) g2_dma2(sw_src + kt, s_dst);
@@ -332,6 +342,13 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // The 32 MFMAs of a K tile run as ONE software pipeline.  (1) The scale-and-add of product n is issued behind MFMA
+    // n + 2, each statement fenced by a sched_barrier of its own: hipcc otherwise sinks every product's FMAs directly under
+    // its MFMA (s_nop 11 + two v_pk_fma per MFMA in the first version's ISA - the matrix pipe idle for a third of every
+    // 32-cycle slot, the packed FMAs costing more issue time than four scalar ones).  (2) The A fragments and row scales come
+    // in four groups of two 16-row tiles; group g + 1 is requested before group g's MFMAs, so only the first group's LDS
+    // latency is exposed per K tile (the first version read four tiles, waited, multiplied, twice per K tile).
+    // (3) Scalar FMAs on purpose: beside MFMAs a v_pk_fma_f32 costs more than the two v_fma_f32 it replaces.
     for (int kt = 0; kt < KB; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < KB) stage(kt + 1, buf ^ 1);
@@ -346,31 +363,51 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
         }
         // (a sub-dword LDS-DMA still strides the lanes by 4 bytes: lane l's 16 bits land at +4l, zero-extended)
         const float swv = to_f(*reinterpret_cast<const bf16*>(Ss + 1024 + (wc >> 1) * 4));   // this wave's 64 columns lie in one block
+        i32x8_g fa[2][2];
+        f32x4_g sraw[2];        // one set: a group's raw row scales are consumed (x the block scale) before the next group's are requested
+        auto load_group = [&](int g, int slot) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            i32x8_g fa[4];
-            f32x4_g sc[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int off = (half * 4 + i) * 2048;
+            for (int u = 0; u < 2; ++u) {
+                const int off = (2 * g + u) * 2048;
                 const uint4 lo = *reinterpret_cast<const uint4*>(As + off + f_lo), hi = *reinterpret_cast<const uint4*>(As + off + f_hi);
-                fa[i] = i32x8_g{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-                sc[i] = *reinterpret_cast<const f32x4_g*>(Ss + (wr * 128 + (half * 4 + i) * 16 + q * 4) * 4) * swv;
+                fa[slot][u] = i32x8_g{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+                sraw[u] = *reinterpret_cast<const f32x4_g*>(Ss + (wr * 128 + (2 * g + u) * 16 + q * 4) * 4);
             }
-            // software-pipelined by one: the scale-and-add of product n runs under MFMA n+1 (written the obvious way,
-            // every MFMA is followed by the FMAs that wait for its own result: MFMA latency exposed 16 times)
-            __builtin_amdgcn_s_setprio(1);
-            f32x4_g tp = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[0], fb[0], f32x4_g{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
-#pragma unroll
-            for (int n = 1; n < 16; ++n) {
-                const f32x4_g tc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[n >> 2], fb[n & 3], f32x4_g{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
-                acc[half * 4 + ((n - 1) >> 2)][(n - 1) & 3] += tp * sc[(n - 1) >> 2];
-                __builtin_amdgcn_sched_barrier(0);
-                tp = tc;
-            }
-            acc[half * 4 + 3][3] += tp * sc[3];
-            __builtin_amdgcn_s_setprio(0);
-        }
+        };
+        load_group(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4_g t[3];
+        float sc[2][2][4];      // [slot][tile of the group][row]
+#define G2F_FMA(NPREV)                                                                                              \
+    {                                                                                                               \
+        constexpr int g_ = (NPREV) >> 3, u_ = ((NPREV) >> 2) & 1, j_ = (NPREV) & 3, i_ = 2 * g_ + u_;               \
+        asm volatile("" : "+v"(t[(NPREV) % 3]));      /* ordered behind the MFMA issued just above (volatile asm statements keep their order) */ \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) acc[i_][j_][r] = fmaf(t[(NPREV) % 3][r], sc[g_ & 1][u_][r], acc[i_][j_][r]); \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+    }
+#define G2F_STEP(N)                                                                                                 \
+    {                                                                                                               \
+        constexpr int g_ = (N) >> 3, u_ = ((N) >> 2) & 1, j_ = (N) & 3;                                            \
+        if constexpr (((N) & 7) == 0) {                                                                             \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                           \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) sc[g_ & 1][u][r] = sraw[u][r] * swv;                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+            if constexpr (g_ < 3) { load_group(g_ + 1, (g_ + 1) & 1); __builtin_amdgcn_sched_barrier(0); }          \
+        }                                                                                                           \
+        t[(N) % 3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[g_ & 1][u_], fb[j_], f32x4_g{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0); \
+        asm volatile("" : "+v"(t[(N) % 3]));          /* pins this MFMA here: instruction selection otherwise sinks every product's FMAs under its own MFMA, sched_barriers notwithstanding */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        if constexpr ((N) >= 2) G2F_FMA((N) - 2)                                                                    \
+    }
+        __builtin_amdgcn_s_setprio(1);
+        G2F_STEP(0) G2F_STEP(1) G2F_STEP(2) G2F_STEP(3) G2F_STEP(4) G2F_STEP(5) G2F_STEP(6) G2F_STEP(7)
+        G2F_STEP(8) G2F_STEP(9) G2F_STEP(10) G2F_STEP(11) G2F_STEP(12) G2F_STEP(13) G2F_STEP(14) G2F_STEP(15)
+        G2F_STEP(16) G2F_STEP(17) G2F_STEP(18) G2F_STEP(19) G2F_STEP(20) G2F_STEP(21) G2F_STEP(22) G2F_STEP(23)
+        G2F_STEP(24) G2F_STEP(25) G2F_STEP(26) G2F_STEP(27) G2F_STEP(28) G2F_STEP(29) G2F_STEP(30) G2F_STEP(31)
+        G2F_FMA(30) G2F_FMA(31)
+        __builtin_amdgcn_s_setprio(0);
+#undef G2F_STEP
+#undef G2F_FMA
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }

@@ -1,7 +1,7 @@
 // Op-level GEMV entry points (M = 1..8 activation rows against an [N,K] weight).
-// See gemv_core.cuh for the kernel design.
+// See gemv_core.hip.h for the kernel design.
 
-#include "gemv_core.cuh"
+#include "gemv_core.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {

@@ -3,7 +3,7 @@
 // else one 256-thread block per row; fp32 math, one rounding on store
 // (reference: native/ops/nn/norm_kernels.cuh:32-584, 32-lane shuffles there, 64 here).
 
-#include "pgk_device.cuh"
+#include "pgk_device.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {

@@ -13,7 +13,7 @@
 // head, not once per query head); each lane group keeps its own online-softmax state, merged through LDS at the end;
 // slices are merged by a second tiny kernel.  HBM-bound on the KV bytes of the live context.
 
-#include "attn_core.cuh"
+#include "attn_core.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {

@@ -22,9 +22,9 @@
 // Reference: the same projections go through cuBLASLt / CUTLASS 128x128 tiles with separate rmsnorm / rope / silu /
 // mul launches (src/pygpukit/llm/layers/attention.py, mlp.py; native/ops/matmul/matmul.cu:142-235).
 
-#include "gemv_core.cuh"
+#include "gemv_core.hip.h"
 #include "pgk_internal.h"
-#include "pkgemm.cuh"
+#include "pkgemm.hip.h"
 
 namespace pgk {
 

@@ -4,7 +4,7 @@
 // Every reduction is a fixed two-level tree (per-workgroup partials in fp32, then one workgroup over the partials),
 // so a result does not depend on scheduling: same bits on every run.
 
-#include "pgk_device.cuh"
+#include "pgk_device.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {

@@ -35,7 +35,7 @@
 //   * otherwise (top_k > 1024, short rows, or no scratch buffer as inside a user's stream capture): one 1024-thread
 //     workgroup walks the row with coalesced loads: max, count / mass descent, indexed draw.
 
-#include "pgk_device.cuh"
+#include "pgk_device.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {

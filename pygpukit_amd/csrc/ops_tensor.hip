@@ -1,7 +1,7 @@
 // Layout shuffles, embedding gathers, KV-cache scatter, argmax.  Pure byte movers:
 // 16-byte accesses when alignment allows, LDS-tiled 2-D transpose.
 
-#include "pgk_device.cuh"
+#include "pgk_device.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {

@@ -14,7 +14,7 @@
 // The reference has nothing of this shape (M < 16 goes to cuBLASLt, M >= 16 to 128x128 CUTLASS tiles,
 // native/ops/matmul/matmul.cu:142-235).
 
-#include "gemv_core.cuh"
+#include "gemv_core.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {

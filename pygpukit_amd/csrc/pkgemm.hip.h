@@ -1,7 +1,7 @@
 // Packed-weight skinny GEMM (ops_pkgemm.hip): arguments and entry points shared with the engine.
 #pragma once
 
-#include "pgk_device.cuh"
+#include "pgk_device.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {

@@ -13,7 +13,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "pgk_device.cuh"
+#include "pgk_device.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {

@@ -1,6 +1,6 @@
 """Time pgk_sdpa_causal (prefill) : TFLOP/s = 4 S^2 D Hq / 2 per launch.  usage: attn_bench.py Hq Hkv S D [...]"""
-import ctypes as C, sys, numpy as np
-sys.path.insert(0, '.')
+import ctypes as C, os, sys, numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from pygpukit_amd import _hip
 _hip.require_device()
 a = [int(x) for x in sys.argv[1:]]

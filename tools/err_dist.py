@@ -19,7 +19,7 @@ if fmt == "fp8":
         d = dict(lw)
         for names in (("q", "k", "v"), ("o",), ("gate", "up"), ("down",)):
             fused = np.concatenate([lw[n] for n in names], axis=0)
-            deq = O.dequantize_fp8_e4m3_block(*O.quantize_fp8_e4m3_block(fused))
+            deq = (O.dequantize_fp8_e4m3_block_w8a16_gemm if os.environ.get('ORACLE_W8A16_GEMM', '1') == '1' else O.dequantize_fp8_e4m3_block)(*O.quantize_fp8_e4m3_block(fused))
             r = 0
             for n in names:
                 d[n] = deq[r:r + lw[n].shape[0]]

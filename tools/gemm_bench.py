@@ -1,7 +1,7 @@
 """Time the C-ABI GEMMs at prefill shapes: TFLOP/s against the dense MFMA peak.
 usage: gemm_bench.py {bf16|w8a16|fp8} M N K [M N K ...]"""
-import ctypes as C, sys, numpy as np
-sys.path.insert(0, '.')
+import ctypes as C, os, sys, numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from pygpukit_amd import _hip
 
 PGK_BF16 = 3

@@ -216,7 +216,7 @@ pgk_status gemm_fp8_nt(const uint8_t* a, const float* sa, const uint8_t* w, cons
                        int N, int K, hipStream_t st) {
     PGK_REQUIRE(M >= 1 && N >= 1 && K >= 128 && K % 128 == 0, "gemm_fp8: K=%d must be a positive multiple of 128 (M=%d N=%d)", K, M, N);
     // enough 256 x 256 tiles to fill the chip: the LDS-DMA structure (ops_gemm256.hip)
-    if (want_gemm256(M, N)) return gemm256_fp8_nt(a, sa, w, sw, c, accum_f32, M, N, K, st);
+    if (want_gemm256(M, N) && M % 256 == 0 && N % 256 == 0) return gemm256_fp8_nt(a, sa, w, sw, c, accum_f32, M, N, K, st);
     constexpr size_t LDS = 4 * (size_t)F8_TILE + 2 * F8_BM * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {

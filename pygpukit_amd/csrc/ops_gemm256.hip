@@ -31,6 +31,9 @@ constexpr int G2_TILE = 256 * 128;   // bytes of one operand tile
 // byte offset of 16-byte chunk c (0..7) of row r in a [rows][128 B] tile
 __device__ __forceinline__ int g2_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
+// fp8 image swizzle (see gemm256_fp8_kernel): (r & 7) ^ (5 for rows 8-15 of every 16)
+__device__ __forceinline__ int g2_sw8(int r) { return (r & 7) ^ ((r & 8) ? 5 : 0); }
+
 // One LDS-DMA wave-instruction: 64 lanes x 16 bytes from per-lane global addresses to LDS [lds_addr, +1024).
 // Written as inline asm on purpose: issued through __builtin_amdgcn_global_load_lds, hipcc (ROCm 7.2) puts an
 // s_waitcnt vmcnt(0) in front of the next ds_read of the kernel - it cannot tell the buffer being filled from the
@@ -174,7 +177,10 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_bf16_kernel(const bf16* A,
 // phase after its last reader finished (lgkmcnt(0) before that phase's barrier); its arrival is ordered by a counted
 // vmcnt(8) - two younger stages may stay in flight - at the end of the phase before the first group reads it, which
 // is B(s) for waves 0-3 and A(s) for waves 4-7.  DMAs past the end of K re-read the last stage (never consumed) so the
-// count is constant.  64-byte rows: chunk c of row r at r*64 + ((c ^ ((r >> 2) & 3)) << 4) (conflict-free b128 reads).
+// count is constant.  64-byte rows: chunk c of row r at r*64 + ((c ^ ((r >> 2) & 2)) << 4).  ds_read_b128 is served in the
+// lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32), not in runs of 16 lanes: the first version's swizzle
+// (r >> 2) & 3 was conflict-free for runs of 16 and 2-way conflicted for the real groups (SQ_LDS_BANK_CONFLICT = half of
+// SQ_LDS_IDX_ACTIVE, profiles/r03_gemm_pmc.txt); (r >> 2) & 2 is conflict-free for them (exhaustive check).
 template <int EPI>
 __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A, const bf16* W, const bf16* bias, void* Cv,
                                                                     int M, int N, int K, int ntm, int ntn) {
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A
     const int m0 = tm * G2_BM, n0 = tn * G2_BN;
 
     const int drow = wid * 32 + (lane >> 2);                 // one DMA instruction = 16 rows x 64 B
-    const int dchunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const int dchunk = (lane & 3) ^ ((lane >> 4) & 2);      // = (lane & 3) ^ g2s_sw(row & 15), row & 15 = lane >> 2
     const bf16* a_src0 = A + (size_t)min(m0 + drow, M - 1) * K + dchunk * 8;
     const bf16* a_src1 = A + (size_t)min(m0 + drow + 16, M - 1) * K + dchunk * 8;
     const bf16* w_src0 = W + (size_t)min(n0 + drow, N - 1) * K + dchunk * 8;
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_g{0.f, 0.f, 0.f, 0.f};
-    const int f_off = l15 * 64 + ((q ^ ((l15 >> 2) & 3)) << 4);
+    const int f_off = l15 * 64 + ((q ^ ((l15 >> 2) & 2)) << 4);
     const int a_base = wr * 128 * 64, w_base = HALF + wc * 64 * 64;
     uint4 fa[8], fb[4];
 
@@ -283,13 +289,20 @@ __device__ __forceinline__ void g2_dma2(const void* src, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
 }
 
+__device__ __forceinline__ void g2_dma4_so(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ void g2_dma2_so(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_ushort %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+
 constexpr int G2_SCALE_BYTES = 256 * 4 + 256;   // per buffer: 256 fp32 row scales | 64 lanes x 4 B of weight-scale slots (2 used)
 
 template <int EPI>   // 0: bf16 C store; 1: fp32 C +=
 __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* A, const float* sa, const uint8_t* W, const bf16* sw,
                                                                   void* Cv, int M, int N, int K, int ntm, int ntn) {
     extern __shared__ __attribute__((aligned(16))) char g2_smem[];   // A[2] | W[2] | scales[2]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // in an SGPR: it enters the DMAs' scalar bases
     const int wr = wid >> 2, wc = wid & 3, q = lane >> 4, l15 = lane & 15;
     int tm, tn;
     g2_tile_of(blockIdx.x, ntm * ntn, ntm, ntn, tm, tn);
@@ -299,33 +312,47 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
     // DMA sources as (uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset): 8 offset registers instead of 16
     // pointer registers in a kernel that lives at the 256-register line, and the per-K-tile advance is one scalar add.
     // Offsets are relative to the tile's first row (operand tiles span at most 255 rows x K <= 2^31 bytes).
-    const int drow = wid * 32 + (lane >> 3);
-    const int dchunk = (lane & 7) ^ (lane >> 3);
-    const uint8_t* a_tile = A + (size_t)m0 * K;
-    const uint8_t* w_tile = W + (size_t)n0 * K;
-    uint32_t a_off[4], w_off[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a_off[i] = (uint32_t)(min(drow + 8 * i, M - 1 - m0) * K + dchunk * 16);
-        w_off[i] = (uint32_t)(min(drow + 8 * i, N - 1 - n0) * K + dchunk * 16);
-    }
-    // scale DMAs: waves 0-3 fetch 64 row scales each; wave 4 fetches the (up to) two weight-block scales
-    const float* sa_src = sa + (size_t)min(m0 + (wid & 3) * 64 + lane, M - 1) * KB;
-    const bf16* sw_src = sw + (size_t)min(2 * tn + (lane & 1), NB - 1) * KB;
+    // LDS image: [256 rows][128 B], 16-byte chunk c of row r at position c ^ g2_sw8(r).  ds_read_b128 is served in the lane
+    // groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32) - not in runs of 16 lanes - and a fragment read has lanes (q =
+    // lane >> 4, row lane & 15) fetch chunks 2 q / 2 q + 1: with the plain c ^ (r & 7) swizzle of the bf16 image, rows r and
+    // r + 8 of such a group meet in the same banks (SQ_LDS_BANK_CONFLICT = 42 % of the LDS cycles of the first version);
+    // XOR-ing 5 into the rows 8-15 of every 16 separates them for both reads (exhaustive check over the four lane groups).
+    //
+    // DMA sources: (wave-uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset).  Instruction i of a wave moves rows
+    // 32 wid + 8 i + (lane >> 3); the row step 8 i K goes into the scalar base, so a lane needs TWO offsets for all eight
+    // instructions of a stage (even / odd i differ in the swizzle only) - this kernel lives at the 256-register line, and
+    // sixteen 64-bit source pointers (the first version) or eight offsets spill.  Whole tiles only: the caller sends shapes
+    // with M % 256 or N % 256 != 0 to the 128-tile kernel (clamped row offsets are loop-invariant, so hipcc computes all
+    // sixteen up front and spills them - and with them a few accumulators).
+    // The per-lane offsets are RECOMPUTED from the lane id at every stage (a handful of vector instructions per tile): held
+    // across the loop they are spilled at its fullest point, and every reload waits on the vector-memory counter.
+    const uint8_t* a_tile = A + ((size_t)m0 + wid * 32) * K;
+    const uint8_t* w_tile = W + ((size_t)n0 + wid * 32) * K;
+    const float* sa_tile = sa + ((size_t)m0 + (wid & 3) * 64) * KB;      // waves 0-3: 64 row scales each (one per lane)
+    const bf16* sw_tile = sw + (size_t)(2 * tn) * KB;                     // wave 4: the tile's two weight-block scales (lanes 0 / 1)
     const uint32_t lds0 = g2_lds_addr(g2_smem);
+    // operand tiles of K tile kt -> stage buf (branch-free: it is issued from the middle of the MFMA pipeline)
     auto stage = [&](int kt, int buf) {
+        uint32_t ln = (uint32_t)lane;
+        asm volatile("" : "+v"(ln));                                     // opaque: keeps the offsets below out of the loop-invariant set
+        const uint32_t r8 = ln >> 3, c8 = ln & 7;
+        const uint32_t off_e = r8 * (uint32_t)K + ((c8 ^ r8) << 4);      // rows 0-7 of 16: swizzle r & 7
+        const uint32_t off_o = r8 * (uint32_t)K + ((c8 ^ r8 ^ 5u) << 4); // rows 8-15: ^ 5 (g2_sw8)
         const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G2_TILE + wid * 4096);
         const uint32_t w_dst = __builtin_amdgcn_readfirstlane(lds0 + (2 + buf) * G2_TILE + wid * 4096);
-        const uint32_t s_dst = __builtin_amdgcn_readfirstlane(lds0 + 4 * G2_TILE + buf * G2_SCALE_BYTES + (wid < 4 ? wid * 256 : 1024));
         const uint8_t* ab = a_tile + (size_t)kt * 128;
         const uint8_t* wb = w_tile + (size_t)kt * 128;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            g2_dma16_so(ab, a_off[i], a_dst + i * 1024);
-            g2_dma16_so(wb, w_off[i], w_dst + i * 1024);
+            g2_dma16_so(ab + (size_t)8 * i * K, (i & 1) ? off_o : off_e, a_dst + i * 1024);
+            g2_dma16_so(wb + (size_t)8 * i * K, (i & 1) ? off_o : off_e, w_dst + i * 1024);
         }
-        if (wid < 4) g2_dma4(sa_src + kt, s_dst);
-        else if (wid == 4) g2_dma2(sw_src + kt, s_dst);
+    };
+    // scales of K tile kt -> scale stage buf (per-wave branches: issued at the top of a tile, outside the pipeline)
+    auto stage_scales = [&](int kt, int buf) {
+        const uint32_t s_dst = __builtin_amdgcn_readfirstlane(lds0 + 4 * G2_TILE + buf * G2_SCALE_BYTES + (wid < 4 ? wid * 256 : 1024));
+        if (wid < 4) g2_dma4_so(sa_tile + kt, (uint32_t)lane * (uint32_t)(KB * 4), s_dst);
+        else if (wid == 4) g2_dma2_so(sw_tile + kt, ((uint32_t)lane & 1u) * (uint32_t)(KB * 2), s_dst);
     };
 
     f32x4_g acc[8][4];
@@ -335,49 +362,55 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_g{0.f, 0.f, 0.f, 0.f};
 
     // fragment reads: row = base + l15, the lane's 32 bytes are chunks 2q and 2q+1
-    const int f_lo = l15 * 128 + (((2 * q) ^ (l15 & 7)) << 4);
-    const int f_hi = l15 * 128 + (((2 * q + 1) ^ (l15 & 7)) << 4);
+    const int f_lo = l15 * 128 + (((2 * q) ^ g2_sw8(l15)) << 4);
+    const int f_hi = l15 * 128 + (((2 * q + 1) ^ g2_sw8(l15)) << 4);
     const int a_base = wr * 128 * 128, w_base = wc * 64 * 128;
 
+    // The 32 MFMAs of a K tile (4 groups of 2 A row-tiles x 4 B column-tiles) run as one software pipeline:
+    // (1) the scale-and-add of product n is issued behind MFMA n + 2, every MFMA pinned by an empty volatile asm on its result:
+    //     instruction selection otherwise sinks each product's FMAs directly under its own MFMA (s_nop 11 + two v_pk_fma per
+    //     MFMA in the first version's ISA; sched_barrier only binds the later machine scheduler).  Scalar FMAs on purpose:
+    //     beside MFMAs a v_pk_fma_f32 costs more issue time than the two v_fma_f32 it replaces;
+    // (2) A fragments and row scales of group g + 1 are requested before group g's MFMAs;
+    // (3) ONE barrier per K tile, at the start of its last group: by then every wave holds all fragments of tile kt in
+    //     registers (stage kt & 1 is free) and its own share of tile kt + 1 - requested a whole tile earlier - has landed.
+    //     Behind it the DMA of tile kt + 2 is issued: a full tile of MFMAs to land in, and its ~9 x 60 cycles of issue sit
+    //     between MFMAs instead of in front of a tile's first one.  A tile starts with its LDS reads, not with a barrier.
+    //     (The scales of tile kt + 1 - 1 KiB, issued under per-wave branches - are requested at the top of tile kt: their
+    //     stage was last read in tile kt - 1, and a branch inside the pipeline would cut its basic block in two.)
+    //     (Requesting the NEXT tile's first fragments during the last group as well - no LDS round trip at a tile's start -
+    //     needs ~12 registers more than the 256 a wave has here: hipcc spills DMA offsets and reloads them behind vmcnt(0).)
     stage(0, 0);
+    stage_scales(0, 0);
+    stage(min(1, KB - 1), 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // The 32 MFMAs of a K tile run as ONE software pipeline.  (1) The scale-and-add of product n is issued behind MFMA
-    // n + 2, each statement fenced by a sched_barrier of its own: hipcc otherwise sinks every product's FMAs directly under
-    // its MFMA (s_nop 11 + two v_pk_fma per MFMA in the first version's ISA - the matrix pipe idle for a third of every
-    // 32-cycle slot, the packed FMAs costing more issue time than four scalar ones).  (2) The A fragments and row scales come
-    // in four groups of two 16-row tiles; group g + 1 is requested before group g's MFMAs, so only the first group's LDS
-    // latency is exposed per K tile (the first version read four tiles, waited, multiplied, twice per K tile).
-    // (3) Scalar FMAs on purpose: beside MFMAs a v_pk_fma_f32 costs more than the two v_fma_f32 it replaces.
+    auto ldfrag = [&](const char* base) -> i32x8_g {
+        const uint4 lo = *reinterpret_cast<const uint4*>(base + f_lo), hi = *reinterpret_cast<const uint4*>(base + f_hi);
+        return i32x8_g{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    };
     for (int kt = 0; kt < KB; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KB) stage(kt + 1, buf ^ 1);
+        stage_scales(min(kt + 1, KB - 1), buf ^ 1);
         const char* As = g2_smem + buf * G2_TILE + a_base;
         const char* Ws = g2_smem + (2 + buf) * G2_TILE + w_base;
         const char* Ss = g2_smem + 4 * G2_TILE + buf * G2_SCALE_BYTES;
-        i32x8_g fb[4];
+        i32x8_g fb[4], fa[2][2];
+        f32x4_g t[3], sraw[2];
+        float sc[2][2][4];      // [slot][row-tile of the group][row]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint4 lo = *reinterpret_cast<const uint4*>(Ws + j * 2048 + f_lo), hi = *reinterpret_cast<const uint4*>(Ws + j * 2048 + f_hi);
-            fb[j] = i32x8_g{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-        }
+        for (int j = 0; j < 4; ++j) fb[j] = ldfrag(Ws + j * 2048);
         // (a sub-dword LDS-DMA still strides the lanes by 4 bytes: lane l's 16 bits land at +4l, zero-extended)
         const float swv = to_f(*reinterpret_cast<const bf16*>(Ss + 1024 + (wc >> 1) * 4));   // this wave's 64 columns lie in one block
-        i32x8_g fa[2][2];
-        f32x4_g sraw[2];        // one set: a group's raw row scales are consumed (x the block scale) before the next group's are requested
         auto load_group = [&](int g, int slot) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int off = (2 * g + u) * 2048;
-                const uint4 lo = *reinterpret_cast<const uint4*>(As + off + f_lo), hi = *reinterpret_cast<const uint4*>(As + off + f_hi);
-                fa[slot][u] = i32x8_g{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+                fa[slot][u] = ldfrag(As + (2 * g + u) * 2048);
                 sraw[u] = *reinterpret_cast<const f32x4_g*>(Ss + (wr * 128 + (2 * g + u) * 16 + q * 4) * 4);
             }
         };
         load_group(0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        f32x4_g t[3];
-        float sc[2][2][4];      // [slot][tile of the group][row]
 #define G2F_FMA(NPREV)                                                                                              \
     {                                                                                                               \
         constexpr int g_ = (NPREV) >> 3, u_ = ((NPREV) >> 2) & 1, j_ = (NPREV) & 3, i_ = 2 * g_ + u_;               \
@@ -388,6 +421,12 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
 #define G2F_STEP(N)                                                                                                 \
     {                                                                                                               \
         constexpr int g_ = (N) >> 3, u_ = ((N) >> 2) & 1, j_ = (N) & 3;                                            \
+        if constexpr ((N) == 24) {                                                                                  \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                             \
+            __builtin_amdgcn_s_barrier();                                                                           \
+            stage(min(kt + 2, KB - 1), buf);          /* past the end: re-reads the last tile into a stage nobody reads any more (no branch inside the pipeline) */ \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+        }                                                                                                           \
         if constexpr (((N) & 7) == 0) {                                                                             \
             _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                           \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) sc[g_ & 1][u][r] = sraw[u][r] * swv;                  \
@@ -395,7 +434,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
             if constexpr (g_ < 3) { load_group(g_ + 1, (g_ + 1) & 1); __builtin_amdgcn_sched_barrier(0); }          \
         }                                                                                                           \
         t[(N) % 3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[g_ & 1][u_], fb[j_], f32x4_g{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0); \
-        asm volatile("" : "+v"(t[(N) % 3]));          /* pins this MFMA here: instruction selection otherwise sinks every product's FMAs under its own MFMA, sched_barriers notwithstanding */ \
+        asm volatile("" : "+v"(t[(N) % 3]));          /* pins this MFMA here */                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
         if constexpr ((N) >= 2) G2F_FMA((N) - 2)                                                                    \
     }
@@ -408,9 +447,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
         __builtin_amdgcn_s_setprio(0);
 #undef G2F_STEP
 #undef G2F_FMA
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // retire the phantom DMAs before the LDS is given back
 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -430,7 +468,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
 
 pgk_status gemm256_fp8_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, void* c, bool accum_f32, int M, int N,
                           int K, hipStream_t st) {
-    PGK_REQUIRE(K % 128 == 0 && K >= 128, "gemm256 fp8: K=%d must be a multiple of 128", K);
+    PGK_REQUIRE(K % 128 == 0 && K >= 128 && M % G2_BM == 0 && N % G2_BN == 0, "gemm256 fp8: M=%d N=%d must be multiples of 256 and K=%d of 128", M, N, K);
     constexpr size_t LDS = 4 * (size_t)G2_TILE + 2 * G2_SCALE_BYTES;
     static bool attr_done = false;
     if (!attr_done) {

@@ -52,9 +52,21 @@ template <int D> __device__ __forceinline__ int fl_k_off(int r, int c) { return 
 // the 32 rows a half-wave reads at one c8 then fall on 32 different bank pairs
 __device__ __forceinline__ int fl_v_off(int d, int c8) { return d * 128 + ((c8 ^ ((d >> 1) & 15)) << 3); }
 
+// KV split (short prompts): nsplit > 1 cuts a query tile's KV tiles into nsplit contiguous runs, one workgroup each; every
+// workgroup leaves a NORMALISED partial output (type T) and its (m, l) per row, and flash_merge_kernel combines them.
+// Without it the causal imbalance sets the time of a short prompt: at S = 2048 with 16 heads there are 256 workgroups -
+// one per CU, the heaviest walks 32 KV tiles, the lightest 2 - and the launch lasts as long as the heaviest (52 us for
+// 17 GFLOP).  Cut in two and dealt heavy-first, two half-runs share a CU and the CUs finish together.
+struct FlashSplit {
+    int nsplit;
+    float* ml;      // [nsplit][Hq][q_len][2]  (m in the exp2 domain, l)
+    void* o;        // [nsplit][q_len][Hq][D] of T
+};
+
 template <class T, int D>
 __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, const T* k, const T* vt, T* out, int hq, int hkv,
-                                                              int q_len, int kv_len, int kv_pad, float scale_log2e, FlashStrides sd) {
+                                                              int q_len, int kv_len, int kv_pad, float scale_log2e, FlashStrides sd,
+                                                              FlashSplit sp) {
     constexpr int NC = D / 8;            // 16-byte chunks per K row
     constexpr int KS = D / 16;           // k-steps of Q.K^T
     constexpr int DT = D / 32;           // 32-row tiles of O^T
@@ -66,12 +78,14 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
     auto Vs = [&](int buf) -> char* { return fl_smem + 2 * K_BYTES + buf * V_BYTES; };
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, ql = lane & 31, h = lane >> 5;
-    // workgroup id -> (kv head, query head in its group, query tile), heavy tiles first
+    // workgroup id -> (kv head, query head in its group, query tile, KV run), heavy tiles first
     const int rep = hq / hkv, nqt = (q_len + FL_BQ - 1) / FL_BQ;
     const int id = blockIdx.x;
     const int kvh = id % hkv, rest = id / hkv;
     const int head = kvh * rep + rest % rep;
-    const int qt = nqt - 1 - rest / rep;
+    const int rest2 = rest / rep;
+    const int split = rest2 % sp.nsplit;
+    const int qt = nqt - 1 - rest2 / sp.nsplit;
     const int qw0 = qt * FL_BQ + wid * 32;          // first query row of this wave
     const int causal_off = kv_len - q_len;
     const T* qh = q + (size_t)head * sd.qh;
@@ -105,7 +119,9 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
 
     const int q_last = min(qt * FL_BQ + FL_BQ - 1, q_len - 1);
     const int kv_end = min(kv_len, causal_off + q_last + 1);
-    const int nt = (kv_end + FL_BKV - 1) / FL_BKV;
+    const int nt_all = (kv_end + FL_BKV - 1) / FL_BKV;
+    // this workgroup's run of KV tiles [t0, t1)
+    const int t0 = (int)((long long)nt_all * split / sp.nsplit), t1 = (int)((long long)nt_all * (split + 1) / sp.nsplit);
 
     // staging in NAMED registers (an array here ends up in scratch memory at this register pressure, see
     // ops_fp8_gemm.hip): chunk i of this thread is c = tid + 256 i; KCH = VCH = D / 32 chunks each
@@ -121,7 +137,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
     // last tile clamps its rows.
     const uint32_t ko0 = (uint32_t)(kr * sd.ks + kc16 * 8), ko_step = (uint32_t)(KR_STEP * sd.ks);
     const uint32_t vo0 = (uint32_t)(vd * kv_pad + vc * 8), vo_step = (uint32_t)(32 * kv_pad);
-    auto load_tile = [&](int t) {
+    auto load_k = [&](int t) {
         const int kv0 = t * FL_BKV;
         if (kv0 + FL_BKV <= kv_len) {      // wave-uniform
             const T* kt = kh + (size_t)kv0 * sd.ks;
@@ -139,7 +155,9 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
                 rk3 = *reinterpret_cast<const uint4*>(k_src(kv0, 3));
             }
         }
-        const T* vtile = vh + kv0;
+    };
+    auto load_v = [&](int t) {
+        const T* vtile = vh + t * FL_BKV;
         rv0 = *reinterpret_cast<const uint4*>(vtile + vo0);
         rv1 = *reinterpret_cast<const uint4*>(vtile + vo0 + vo_step);
         if constexpr (VCH == 4) {
@@ -151,15 +169,17 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
         *reinterpret_cast<uint2*>(base + fl_v_off(d, 2 * vc)) = make_uint2(x.x, x.y);
         *reinterpret_cast<uint2*>(base + fl_v_off(d, 2 * vc + 1)) = make_uint2(x.z, x.w);
     };
-    auto store_tile = [&](int buf) {
+    auto store_k = [&](int buf) {
         char* kb = Ks(buf);
-        char* vb = Vs(buf);
         *reinterpret_cast<uint4*>(kb + fl_k_off<D>(kr, kc16)) = rk0;
         *reinterpret_cast<uint4*>(kb + fl_k_off<D>(kr + KR_STEP, kc16)) = rk1;
         if constexpr (KCH == 4) {
             *reinterpret_cast<uint4*>(kb + fl_k_off<D>(kr + 2 * KR_STEP, kc16)) = rk2;
             *reinterpret_cast<uint4*>(kb + fl_k_off<D>(kr + 3 * KR_STEP, kc16)) = rk3;
         }
+    };
+    auto store_v = [&](int buf) {
+        char* vb = Vs(buf);
         put_v(vb, vd, rv0);
         put_v(vb, vd + 32, rv1);
         if constexpr (VCH == 4) {
@@ -167,32 +187,53 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
             put_v(vb, vd + 96, rv3);
         }
     };
+    // S^T = K . Q^T of one tile: two 32-kv sub-tiles (rows = positions, column = this lane's query)
+    auto qk = [&](int buf, f32x16_fl& s0, f32x16_fl& s1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const uint4 a0 = *reinterpret_cast<const uint4*>(Ks(buf) + fl_k_off<D>(ql, 2 * ks + h));
+            const uint4 a1 = *reinterpret_cast<const uint4*>(Ks(buf) + fl_k_off<D>(32 + ql, 2 * ks + h));
+            s0 = mfma32<T>(a0, qf[ks], s0);
+            s1 = mfma32<T>(a1, qf[ks], s1);
+        }
+    };
+    // tiles entirely above this wave's diagonal contribute nothing (wave-uniform)
+    auto live = [&](int t) -> bool { return t < t1 && t * FL_BKV <= causal_off + qw0 + 31; };
 
-    load_tile(0);
-    store_tile(0);
+    // Software pipeline across tiles: iteration t multiplies S(t + 1) = K(t + 1) . Q^T while the softmax of S(t) - which is
+    // pure vector work on 32 scores per lane - runs under those MFMAs, then O += V(t) . P(t).  (One tile per iteration - QK,
+    // softmax, PV in sequence - left the matrix pipe idle for the whole softmax of each wave: 41 % MFMA-busy with two waves per
+    // SIMD, profiles/r03_flash_pmc.txt.)  LDS at the start of iteration t: K(t + 1) in K[(t + 1) & 1], V(t) in V[t & 1]; the
+    // iteration fetches K(t + 2) and V(t + 1) into registers and parks them in K[t & 1] / V[(t + 1) & 1] - both last read one
+    // barrier ago - before its closing barrier.
+    f32x16_fl sc0, sc1, sn0, sn1;
+    if (t0 < t1) {
+        load_k(t0);
+        load_v(t0);
+        store_k(t0 & 1);
+        store_v(t0 & 1);
+        if (t0 + 1 < t1) { load_k(t0 + 1); store_k((t0 + 1) & 1); }
+    }
     // Retire the Q loads HERE: if they are still counted as pending at the loop header, hipcc's conservative
     // vmcnt bookkeeping waits for them in every iteration - behind the tile prefetch issued at the top of the
     // loop, i.e. it drains the prefetch before the first MFMA.
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks].x), "v"(qf[ks].y), "v"(qf[ks].z), "v"(qf[ks].w));
     __syncthreads();
-    for (int t = 0; t < nt; ++t) {
+    if (live(t0)) qk(t0 & 1, sc0, sc1);
+    __syncthreads();          // K[t0 & 1] is refilled at the end of the first iteration: every wave's S(t0) reads come first
+    typedef uint32_t fl_u32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) const volatile fl_u32x2* fl_lds_cv64;     // volatile drops the inferred address space: say it
+    for (int t = t0; t < t1; ++t) {
         const int buf = t & 1, kv0 = t * FL_BKV;
-        if (t + 1 < nt) load_tile(t + 1);
-        // tiles entirely above this wave's diagonal contribute nothing (wave-uniform)
-        if (kv0 <= causal_off + qw0 + 31) {
-            // ---- S^T = K . Q^T : two 32-kv sub-tiles ----
-            f32x16_fl s0, s1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const uint4 a0 = *reinterpret_cast<const uint4*>(Ks(buf) + fl_k_off<D>(ql, 2 * ks + h));
-                const uint4 a1 = *reinterpret_cast<const uint4*>(Ks(buf) + fl_k_off<D>(32 + ql, 2 * ks + h));
-                s0 = mfma32<T>(a0, qf[ks], s0);
-                s1 = mfma32<T>(a1, qf[ks], s1);
-            }
-            // ---- scale, mask, online softmax (this lane: query qw0 + ql, kv rows (r&3) + 8(r>>2) + 4h of each sub-tile) ----
+        if (t + 2 < t1) load_k(t + 2);
+        if (t + 1 < t1) load_v(t + 1);
+        const bool cur = live(t), nxt = live(t + 1);
+        if (nxt) qk(buf ^ 1, sn0, sn1);
+        if (cur) {
+            // ---- mask, online softmax (this lane: query qw0 + ql, kv rows (r&3) + 8(r>>2) + 4h of each sub-tile) ----
             const bool need_mask = kv0 + FL_BKV - 1 > causal_off + qw0 || kv0 + FL_BKV > kv_len;   // wave-uniform
             const int lim = min(causal_off + qw0 + ql, kv_len - 1) - kv0 - 4 * h;                  // local kv row <= lim is visible
             float mx = -INFINITY;
@@ -200,14 +241,14 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kvl = (r & 3) + 8 * (r >> 2);
-                    s0[r] = kvl <= lim ? s0[r] : -INFINITY;
-                    s1[r] = 32 + kvl <= lim ? s1[r] : -INFINITY;
+                    sc0[r] = kvl <= lim ? sc0[r] : -INFINITY;
+                    sc1[r] = 32 + kvl <= lim ? sc1[r] : -INFINITY;
                 }
             }
             // (this file is built with -fno-honor-nans: without it every operand of a max is first canonicalised with a
             // v_max_f32 x, x, x of its own - 60 instructions for these 32 values instead of 16 v_max3_f32)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(fmaxf(s0[r], s1[r]), fmaxf(s0[r + 1], s1[r + 1])), mx);
+            for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(fmaxf(sc0[r], sc1[r]), fmaxf(sc0[r + 1], sc1[r + 1])), mx);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             // Deferred rescale: the reference point of a row only moves when its maximum grew by more than 6 (log2
             // domain), so probabilities stay <= 64 (exact in fp32 sums, fine in 16-bit P) and on most tiles - for the whole
@@ -219,9 +260,9 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
             float ls = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_use);
-                s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_use);
-                ls += s0[r] + s1[r];
+                sc0[r] = __builtin_amdgcn_exp2f(sc0[r] - m_use);
+                sc1[r] = __builtin_amdgcn_exp2f(sc1[r] - m_use);
+                ls += sc0[r] + sc1[r];
             }
             l_run = l_run * alpha + ls;
             m_run = m_new;
@@ -238,19 +279,17 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
             // VOLATILE: left ordinary, hipcc pairs those of tiles i and i + 2 into ds_read2st64_b64, which is served 16 lanes
             // at a time on a 32-bank modulus (2-way conflicts, half the rate); the first version kept them apart by laundering
             // every address through an empty asm - a v_mov + v_add per read, 64 vector instructions per tile.
-            typedef uint32_t fl_u32x2 __attribute__((ext_vector_type(2)));
-            typedef __attribute__((address_space(3))) const volatile fl_u32x2* fl_lds_cv64;     // volatile drops the inferred address space: say it
             const char* vrow = Vs(buf) + ql * 128;
             const int vsw = (ql >> 1) & 15;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 uint4 pb;
                 if (s < 2) {
-                    pb = make_uint4(pack16x2<T>(s0[8 * s + 0], s0[8 * s + 1]), pack16x2<T>(s0[8 * s + 2], s0[8 * s + 3]),
-                                    pack16x2<T>(s0[8 * s + 4], s0[8 * s + 5]), pack16x2<T>(s0[8 * s + 6], s0[8 * s + 7]));
+                    pb = make_uint4(pack16x2<T>(sc0[8 * s + 0], sc0[8 * s + 1]), pack16x2<T>(sc0[8 * s + 2], sc0[8 * s + 3]),
+                                    pack16x2<T>(sc0[8 * s + 4], sc0[8 * s + 5]), pack16x2<T>(sc0[8 * s + 6], sc0[8 * s + 7]));
                 } else {
-                    pb = make_uint4(pack16x2<T>(s1[8 * (s - 2) + 0], s1[8 * (s - 2) + 1]), pack16x2<T>(s1[8 * (s - 2) + 2], s1[8 * (s - 2) + 3]),
-                                    pack16x2<T>(s1[8 * (s - 2) + 4], s1[8 * (s - 2) + 5]), pack16x2<T>(s1[8 * (s - 2) + 6], s1[8 * (s - 2) + 7]));
+                    pb = make_uint4(pack16x2<T>(sc1[8 * (s - 2) + 0], sc1[8 * (s - 2) + 1]), pack16x2<T>(sc1[8 * (s - 2) + 2], sc1[8 * (s - 2) + 3]),
+                                    pack16x2<T>(sc1[8 * (s - 2) + 4], sc1[8 * (s - 2) + 5]), pack16x2<T>(sc1[8 * (s - 2) + 6], sc1[8 * (s - 2) + 7]));
                 }
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
@@ -261,8 +300,10 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
                 }
             }
         }
-        if (t + 1 < nt) store_tile(buf ^ 1);
+        if (t + 2 < t1) store_k(buf);
+        if (t + 1 < t1) store_v(buf ^ 1);
         __syncthreads();
+        if (nxt) { sc0 = sn0; sc1 = sn1; }
     }
 
     // ---- normalise and store: lane = query row, registers 4g..4g+3 of tile i are d = 32i + 8g + 4h .. +3 ----
@@ -270,7 +311,8 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     const int qrow = qw0 + ql;
     if (qrow < q_len) {
-        T* orow = out + (size_t)head * sd.oh + (size_t)qrow * sd.os;
+        T* orow = sp.nsplit > 1 ? reinterpret_cast<T*>(sp.o) + (((size_t)split * q_len + qrow) * hq + head) * D
+                                : out + (size_t)head * sd.oh + (size_t)qrow * sd.os;
 #pragma unroll
         for (int i = 0; i < DT; ++i)
 #pragma unroll
@@ -280,7 +322,45 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
                 w.y = pack16x2<T>(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
                 *reinterpret_cast<uint2*>(orow + i * 32 + 8 * g + 4 * h) = w;
             }
+        if (sp.nsplit > 1 && h == 0) {
+            float* ml = sp.ml + (((size_t)split * hq + head) * q_len + qrow) * 2;
+            ml[0] = m_run;
+            ml[1] = l_tot;
+        }
     }
+}
+
+// out[q][head][:] = sum_s w_s o_s / sum_s w_s,  w_s = l_s 2^(m_s - max m): one thread per 8 output elements
+template <class T, int D>
+__global__ __launch_bounds__(256) void flash_merge_kernel(const float* ml, const T* po, T* out, int hq, int q_len, int nsplit, long long oh, long long os) {
+    constexpr int CPR = D / 8;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t nrow = (size_t)q_len * hq;
+    if (gid >= nrow * CPR) return;
+    const size_t rowi = gid / CPR;
+    const int c = (int)(gid % CPR), qrow = (int)(rowi / hq), head = (int)(rowi % hq);
+    float mstar = -INFINITY;
+    for (int s2 = 0; s2 < nsplit; ++s2) mstar = fmaxf(mstar, ml[(((size_t)s2 * hq + head) * q_len + qrow) * 2]);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, den = 0.f;
+    for (int s2 = 0; s2 < nsplit; ++s2) {
+        const float* r = ml + (((size_t)s2 * hq + head) * q_len + qrow) * 2;
+        const float w = (r[1] > 0.f) ? r[1] * __builtin_amdgcn_exp2f(r[0] - mstar) : 0.f;
+        if (w > 0.f) {
+            Vec<T> v;
+            v.load(po + (((size_t)s2 * q_len + qrow) * hq + head) * D + c * 8);
+            float f[8];
+            v.to_float(f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(w, f[j], acc[j]);
+            den += w;
+        }
+    }
+    const float inv = den > 0.f ? 1.f / den : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] *= inv;
+    Vec<T> v;
+    v.from_float(acc);
+    v.store(out + (size_t)head * oh + (size_t)qrow * os + c * 8);
 }
 
 // V [Hkv][kv][D] (element strides kh, ks) -> V^T [Hkv][D][kv_pad], zero beyond kv_len.  One workgroup per
@@ -317,9 +397,30 @@ template <class T, int D>
 static pgk_status flash_launch(const T* q, const T* k, const T* v, T* out, int hq, int hkv, int q_len, int kv_len, float scale,
                                const FlashStrides& sd, hipStream_t st) {
     const int kv_pad = ceil_div(kv_len, 64) * 64;
-    void* vt = nullptr;
-    if (pgk_status r = pgk_malloc(&vt, (size_t)hkv * D * kv_pad * sizeof(T))) return r;
-    transpose_v_kernel<T, D><<<dim3(kv_pad / 64, hkv), 256, 0, st>>>(v, (T*)vt, kv_len, kv_pad, sd.kh, sd.ks);
+    const int nqt = ceil_div(q_len, FL_BQ);
+    // KV runs per query tile: enough workgroups for two per CU (the kernel's occupancy), never more runs than the
+    // shortest useful run of two KV tiles allows for the heaviest query tile
+    int nsplit = 1;
+    {
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        const long long wgs = (long long)nqt * hq;
+        while (nsplit < 4 && wgs * nsplit < 2LL * cus && ceil_div(kv_len, FL_BKV) >= 4 * (nsplit * 2)) nsplit *= 2;
+    }
+    const size_t vt_bytes = (size_t)hkv * D * kv_pad * sizeof(T);
+    const size_t po_bytes = nsplit > 1 ? (size_t)nsplit * q_len * hq * D * sizeof(T) : 0;
+    const size_t ml_bytes = nsplit > 1 ? (size_t)nsplit * hq * q_len * 2 * sizeof(float) : 0;
+    void* ws = nullptr;
+    if (pgk_status r = pgk_malloc(&ws, vt_bytes + po_bytes + ml_bytes + 512)) return r;
+    char* base = (char*)ws;
+    T* vt = (T*)base;
+    FlashSplit sp{nsplit, nullptr, nullptr};
+    if (nsplit > 1) {
+        sp.o = base + ((vt_bytes + 255) & ~(size_t)255);
+        sp.ml = (float*)((char*)sp.o + ((po_bytes + 255) & ~(size_t)255));
+    }
+    transpose_v_kernel<T, D><<<dim3(kv_pad / 64, hkv), 256, 0, st>>>(v, vt, kv_len, kv_pad, sd.kh, sd.ks);
     constexpr size_t LDS = 2 * (size_t)(64 * D * 2) + 2 * (size_t)(D * 128);
     static bool attr_done = false;
     if (LDS > 48 * 1024 && !attr_done) {
@@ -327,11 +428,15 @@ static pgk_status flash_launch(const T* q, const T* k, const T* v, T* out, int h
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_done = true;
     }
-    const int nqt = ceil_div(q_len, FL_BQ);
-    flash_fwd_kernel<T, D><<<nqt * hq, FL_THREADS, LDS, st>>>(q, k, (const T*)vt, out, hq, hkv, q_len, kv_len, kv_pad,
-                                                             scale * 1.4426950408889634f, sd);
-    const hipError_t e = hipGetLastError();
-    pgk_free(vt);   // stream-ordered reuse: later work on this stream runs after the kernels above
+    flash_fwd_kernel<T, D><<<nqt * hq * nsplit, FL_THREADS, LDS, st>>>(q, k, (const T*)vt, out, hq, hkv, q_len, kv_len, kv_pad,
+                                                                      scale * 1.4426950408889634f, sd, sp);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && nsplit > 1) {
+        const size_t work = (size_t)q_len * hq * (D / 8);
+        flash_merge_kernel<T, D><<<(unsigned)((work + 255) / 256), 256, 0, st>>>(sp.ml, (const T*)sp.o, out, hq, q_len, nsplit, sd.oh, sd.os);
+        e = hipGetLastError();
+    }
+    pgk_free(ws);   // stream-ordered reuse: later work on this stream runs after the kernels above
     PGK_CHECK_HIP(e);
     return PGK_OK;
 }

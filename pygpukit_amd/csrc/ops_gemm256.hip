@@ -331,22 +331,28 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
     const float* sa_tile = sa + ((size_t)m0 + (wid & 3) * 64) * KB;      // waves 0-3: 64 row scales each (one per lane)
     const bf16* sw_tile = sw + (size_t)(2 * tn) * KB;                     // wave 4: the tile's two weight-block scales (lanes 0 / 1)
     const uint32_t lds0 = g2_lds_addr(g2_smem);
-    // operand tiles of K tile kt -> stage buf (branch-free: it is issued from the middle of the MFMA pipeline)
-    auto stage = [&](int kt, int buf) {
+    // operand tiles of K tile kt -> stage buf, as eight 1-KiB pieces (piece p: rows 8 (p >> 1) .. + 8 of this wave's 32, A for
+    // even p, W for odd p).  Branch-free: the pieces are issued from the middle of the MFMA pipeline, one behind each MFMA of
+    // a tile's last group - a DMA costs ~60 cycles of issue, which back to back (the first version) is ~500 cycles in which
+    // neither wave of a SIMD issues an MFMA, and behind an MFMA mostly runs under it.
+    auto stage_piece = [&](int kt, int buf, int p, uint32_t off_e, uint32_t off_o) {
+        const int i = p >> 1;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + ((p & 1) ? 2 + buf : buf) * G2_TILE + wid * 4096 + i * 1024);
+        const uint8_t* base = ((p & 1) ? w_tile : a_tile) + (size_t)kt * 128 + (size_t)8 * i * K;
+        g2_dma16_so(base, (i & 1) ? off_o : off_e, dst);
+    };
+    auto stage_offsets = [&](uint32_t& off_e, uint32_t& off_o) {
         uint32_t ln = (uint32_t)lane;
-        asm volatile("" : "+v"(ln));                                     // opaque: keeps the offsets below out of the loop-invariant set
+        asm volatile("" : "+v"(ln));                                     // opaque: keeps the offsets out of the loop-invariant set
         const uint32_t r8 = ln >> 3, c8 = ln & 7;
-        const uint32_t off_e = r8 * (uint32_t)K + ((c8 ^ r8) << 4);      // rows 0-7 of 16: swizzle r & 7
-        const uint32_t off_o = r8 * (uint32_t)K + ((c8 ^ r8 ^ 5u) << 4); // rows 8-15: ^ 5 (g2_sw8)
-        const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G2_TILE + wid * 4096);
-        const uint32_t w_dst = __builtin_amdgcn_readfirstlane(lds0 + (2 + buf) * G2_TILE + wid * 4096);
-        const uint8_t* ab = a_tile + (size_t)kt * 128;
-        const uint8_t* wb = w_tile + (size_t)kt * 128;
+        off_e = r8 * (uint32_t)K + ((c8 ^ r8) << 4);                     // rows 0-7 of 16: swizzle r & 7
+        off_o = r8 * (uint32_t)K + ((c8 ^ r8 ^ 5u) << 4);                // rows 8-15: ^ 5 (g2_sw8)
+    };
+    auto stage = [&](int kt, int buf) {
+        uint32_t off_e, off_o;
+        stage_offsets(off_e, off_o);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            g2_dma16_so(ab + (size_t)8 * i * K, (i & 1) ? off_o : off_e, a_dst + i * 1024);
-            g2_dma16_so(wb + (size_t)8 * i * K, (i & 1) ? off_o : off_e, w_dst + i * 1024);
-        }
+        for (int p = 0; p < 8; ++p) stage_piece(kt, buf, p, off_e, off_o);
     };
     // scales of K tile kt -> scale stage buf (per-wave branches: issued at the top of a tile, outside the pipeline)
     auto stage_scales = [&](int kt, int buf) {
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
     const int f_hi = l15 * 128 + (((2 * q + 1) ^ g2_sw8(l15)) << 4);
     const int a_base = wr * 128 * 128, w_base = wc * 64 * 128;
 
-    // The 32 MFMAs of a K tile (4 groups of 2 A row-tiles x 4 B column-tiles) run as one software pipeline:
+    // The MFMAs run as ONE software pipeline over the whole K loop, 32 per K tile (4 groups of 2 A row-tiles x 4 B column-tiles):
     // (1) the scale-and-add of product n is issued behind MFMA n + 2, every MFMA pinned by an empty volatile asm on its result:
     //     instruction selection otherwise sinks each product's FMAs directly under its own MFMA (s_nop 11 + two v_pk_fma per
     //     MFMA in the first version's ISA; sched_barrier only binds the later machine scheduler).  Scalar FMAs on purpose:
@@ -374,80 +380,106 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
     // (2) A fragments and row scales of group g + 1 are requested before group g's MFMAs;
     // (3) ONE barrier per K tile, at the start of its last group: by then every wave holds all fragments of tile kt in
     //     registers (stage kt & 1 is free) and its own share of tile kt + 1 - requested a whole tile earlier - has landed.
-    //     Behind it the DMA of tile kt + 2 is issued: a full tile of MFMAs to land in, and its ~9 x 60 cycles of issue sit
-    //     between MFMAs instead of in front of a tile's first one.  A tile starts with its LDS reads, not with a barrier.
-    //     (The scales of tile kt + 1 - 1 KiB, issued under per-wave branches - are requested at the top of tile kt: their
-    //     stage was last read in tile kt - 1, and a branch inside the pipeline would cut its basic block in two.)
-    //     (Requesting the NEXT tile's first fragments during the last group as well - no LDS round trip at a tile's start -
-    //     needs ~12 registers more than the 256 a wave has here: hipcc spills DMA offsets and reloads them behind vmcnt(0).)
+    //     Behind it the DMA of tile kt + 2 goes out, one piece behind each MFMA of the group, and the NEXT tile's first
+    //     fragments are requested: group 0's A fragments at once, its row scales two steps later, each B fragment right
+    //     after its last MFMA of this tile (the last group runs column-major for that).  No tile starts with an LDS round
+    //     trip, a burst of DMA issue or a barrier.  Everything inside the pipeline is branch-free - one conditional DMA
+    //     in it cut the basic block in two and made hipcc spill a hundred registers per tile - so the scales of tile
+    //     kt + 1 (1 KiB under per-wave branches) are requested at the top of tile kt; their stage was last read in tile kt - 1.
     stage(0, 0);
     stage_scales(0, 0);
     stage(min(1, KB - 1), 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    i32x8_g fb[4], fa[2][2];
+    f32x4_g t[3];
+    f32x4_g sc[2][2];        // [slot][row-tile of the group]: raw row scales as they come from LDS, multiplied by the block scale in place
+    float swv;
+    uint32_t off_e = 0, off_o = 0;
     auto ldfrag = [&](const char* base) -> i32x8_g {
         const uint4 lo = *reinterpret_cast<const uint4*>(base + f_lo), hi = *reinterpret_cast<const uint4*>(base + f_hi);
         return i32x8_g{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
     };
-    for (int kt = 0; kt < KB; ++kt) {
-        const int buf = kt & 1;
-        stage_scales(min(kt + 1, KB - 1), buf ^ 1);
+    auto load_frags = [&](int buf, int g, int slot) {
         const char* As = g2_smem + buf * G2_TILE + a_base;
-        const char* Ws = g2_smem + (2 + buf) * G2_TILE + w_base;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) fa[slot][u] = ldfrag(As + (2 * g + u) * 2048);
+    };
+    // a group's row scales go into the slot the group BEFORE the previous one used: that one's last two scale-and-adds run
+    // two steps into the next group, so the scales are requested at step 2 of a group, the fragments at step 0
+    auto load_scales = [&](int buf, int g, int slot) {
         const char* Ss = g2_smem + 4 * G2_TILE + buf * G2_SCALE_BYTES;
-        i32x8_g fb[4], fa[2][2];
-        f32x4_g t[3], sraw[2];
-        float sc[2][2][4];      // [slot][row-tile of the group][row]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = ldfrag(Ws + j * 2048);
-        // (a sub-dword LDS-DMA still strides the lanes by 4 bytes: lane l's 16 bits land at +4l, zero-extended)
-        const float swv = to_f(*reinterpret_cast<const bf16*>(Ss + 1024 + (wc >> 1) * 4));   // this wave's 64 columns lie in one block
-        auto load_group = [&](int g, int slot) {
+        for (int u = 0; u < 2; ++u) sc[slot][u] = *reinterpret_cast<const f32x4_g*>(Ss + (wr * 128 + (2 * g + u) * 16 + q * 4) * 4);
+    };
+    // (a sub-dword LDS-DMA still strides the lanes by 4 bytes: lane l's 16 bits land at +4l, zero-extended)
+    auto load_swv = [&](int buf) -> float { return to_f(*reinterpret_cast<const bf16*>(g2_smem + 4 * G2_TILE + buf * G2_SCALE_BYTES + 1024 + (wc >> 1) * 4)); };
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                fa[slot][u] = ldfrag(As + (2 * g + u) * 2048);
-                sraw[u] = *reinterpret_cast<const f32x4_g*>(Ss + (wr * 128 + (2 * g + u) * 16 + q * 4) * 4);
-            }
-        };
-        load_group(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < 4; ++j) fb[j] = ldfrag(g2_smem + 2 * G2_TILE + w_base + j * 2048);
+    load_frags(0, 0, 0);
+    load_scales(0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // step n of a tile: group g = n / 8; groups 0-2 walk (row-tile u, column-tile j) row-major, group 3 column-major
+#define G2F_U(N) (((N) < 24) ? (((N) >> 2) & 1) : ((N) & 1))
+#define G2F_J(N) (((N) < 24) ? ((N) & 3) : (((N) & 7) >> 1))
 #define G2F_FMA(NPREV)                                                                                              \
     {                                                                                                               \
-        constexpr int g_ = (NPREV) >> 3, u_ = ((NPREV) >> 2) & 1, j_ = (NPREV) & 3, i_ = 2 * g_ + u_;               \
+        constexpr int g_ = (NPREV) >> 3, u_ = G2F_U(NPREV), j_ = G2F_J(NPREV), i_ = 2 * g_ + u_;                    \
         asm volatile("" : "+v"(t[(NPREV) % 3]));      /* ordered behind the MFMA issued just above (volatile asm statements keep their order) */ \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) acc[i_][j_][r] = fmaf(t[(NPREV) % 3][r], sc[g_ & 1][u_][r], acc[i_][j_][r]); \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
     }
 #define G2F_STEP(N)                                                                                                 \
     {                                                                                                               \
-        constexpr int g_ = (N) >> 3, u_ = ((N) >> 2) & 1, j_ = (N) & 3;                                            \
+        constexpr int g_ = (N) >> 3, u_ = G2F_U(N), j_ = G2F_J(N);                                                  \
         if constexpr ((N) == 24) {                                                                                  \
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                             \
             __builtin_amdgcn_s_barrier();                                                                           \
-            stage(min(kt + 2, KB - 1), buf);          /* past the end: re-reads the last tile into a stage nobody reads any more (no branch inside the pipeline) */ \
+            stage_offsets(off_e, off_o);                                                                            \
             __builtin_amdgcn_sched_barrier(0);                                                                      \
         }                                                                                                           \
         if constexpr (((N) & 7) == 0) {                                                                             \
+            if constexpr ((N) == 0) swv = load_swv(buf);                                                            \
             _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                           \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) sc[g_ & 1][u][r] = sraw[u][r] * swv;                  \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) sc[g_ & 1][u][r] *= swv;                              \
             __builtin_amdgcn_sched_barrier(0);                                                                      \
-            if constexpr (g_ < 3) { load_group(g_ + 1, (g_ + 1) & 1); __builtin_amdgcn_sched_barrier(0); }          \
+            if constexpr (g_ < 3) load_frags(buf, g_ + 1, (g_ + 1) & 1);                                            \
+            else load_frags(buf ^ 1, 0, 0);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+        }                                                                                                           \
+        if constexpr (((N) & 7) == 2) {                                                                             \
+            if constexpr (g_ < 3) load_scales(buf, g_ + 1, (g_ + 1) & 1);                                           \
+            else load_scales(buf ^ 1, 0, 0);                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
         }                                                                                                           \
         t[(N) % 3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[g_ & 1][u_], fb[j_], f32x4_g{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0); \
         asm volatile("" : "+v"(t[(N) % 3]));          /* pins this MFMA here */                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
+        if constexpr ((N) >= 24) {                    /* one DMA piece of tile kt + 2 behind each MFMA of the last group (past the end: re-reads the last tile into a stage nobody reads any more) */ \
+            stage_piece(min(kt + 2, KB - 1), buf, (N) - 24, off_e, off_o);                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+        }                                                                                                           \
+        if constexpr ((N) >= 24 && ((N) & 1) == 1) {  /* last use of column-tile j_ in this tile: fetch the next tile's */ \
+            fb[j_] = ldfrag(g2_smem + (2 + (buf ^ 1)) * G2_TILE + w_base + j_ * 2048);                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+        }                                                                                                           \
         if constexpr ((N) >= 2) G2F_FMA((N) - 2)                                                                    \
     }
-        __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
+    for (int kt = 0; kt < KB; ++kt) {
+        const int buf = kt & 1;
+        stage_scales(min(kt + 1, KB - 1), buf ^ 1);
         G2F_STEP(0) G2F_STEP(1) G2F_STEP(2) G2F_STEP(3) G2F_STEP(4) G2F_STEP(5) G2F_STEP(6) G2F_STEP(7)
         G2F_STEP(8) G2F_STEP(9) G2F_STEP(10) G2F_STEP(11) G2F_STEP(12) G2F_STEP(13) G2F_STEP(14) G2F_STEP(15)
         G2F_STEP(16) G2F_STEP(17) G2F_STEP(18) G2F_STEP(19) G2F_STEP(20) G2F_STEP(21) G2F_STEP(22) G2F_STEP(23)
         G2F_STEP(24) G2F_STEP(25) G2F_STEP(26) G2F_STEP(27) G2F_STEP(28) G2F_STEP(29) G2F_STEP(30) G2F_STEP(31)
         G2F_FMA(30) G2F_FMA(31)
-        __builtin_amdgcn_s_setprio(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
 #undef G2F_STEP
 #undef G2F_FMA
-    }
+#undef G2F_U
+#undef G2F_J
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // retire the phantom DMAs before the LDS is given back
 
 #pragma unroll

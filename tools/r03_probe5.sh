@@ -15,6 +15,9 @@ timeout -k 10 200 python tools/prefill_prof.py 2048 5 > $O/pf.log 2>&1 || exit 1
 timeout -k 10 300 python tools/config5_prefill.py 4096 8 2 > $O/c5.log 2>&1 || echo "config5 failed" | tee -a $O/progress.log
 timeout -k 10 120 python tools/decode_prof.py 1 100 2048 fp8 graph >> $O/dp.log 2>&1 || exit 1
 timeout -k 10 120 python tools/decode_prof.py 64 50 128 fp8 graph >> $O/dp.log 2>&1 || exit 1
+timeout -k 10 120 python tools/decode_prof.py 8 100 128 bf16 graph >> $O/dp.log 2>&1 || exit 1
+timeout -k 10 120 python tools/decode_prof.py 16 100 128 bf16 graph >> $O/dp.log 2>&1 || exit 1
+timeout -k 10 120 python tools/decode_prof.py 1 200 128 bf16 graph >> $O/dp.log 2>&1 || exit 1
 cat $O/gemm_fp8.log $O/attn.log $O/pf.log $O/dp.log; tail -6 $O/c5.log
 echo "== PMC flash / fp8" | tee -a $O/progress.log
 cd /tmp && export TMPDIR=/tmp

@@ -202,19 +202,16 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
     // tiles entirely above this wave's diagonal contribute nothing (wave-uniform)
     auto live = [&](int t) -> bool { return t < t1 && t * FL_BKV <= causal_off + qw0 + 31; };
 
-    // Software pipeline across tiles: iteration t multiplies S(t + 1) = K(t + 1) . Q^T while the softmax of S(t) - which is
-    // pure vector work on 32 scores per lane - runs under those MFMAs, then O += V(t) . P(t).  (One tile per iteration - QK,
-    // softmax, PV in sequence - left the matrix pipe idle for the whole softmax of each wave: 41 % MFMA-busy with two waves per
-    // SIMD, profiles/r03_flash_pmc.txt.)  LDS at the start of iteration t: K(t + 1) in K[(t + 1) & 1], V(t) in V[t & 1]; the
-    // iteration fetches K(t + 2) and V(t + 1) into registers and parks them in K[t & 1] / V[(t + 1) & 1] - both last read one
-    // barrier ago - before its closing barrier.
-    f32x16_fl sc0, sc1, sn0, sn1;
+    // One KV tile per iteration: S = K . Q^T, softmax, O += V . P; the global loads of tile t + 1 are issued before the MFMAs of
+    // tile t and parked in the other LDS buffer after them: one barrier per tile.  (Tried in round 3: multiplying S(t + 1) under
+    // the softmax of S(t).  As two conditional blocks hipcc keeps them apart - QK block, 64 register copies, softmax - and
+    // the kernel lost 2 %; it needs a branch-free, two-tile-unrolled body to interleave.)
+    f32x16_fl sc0, sc1;
     if (t0 < t1) {
         load_k(t0);
         load_v(t0);
         store_k(t0 & 1);
         store_v(t0 & 1);
-        if (t0 + 1 < t1) { load_k(t0 + 1); store_k((t0 + 1) & 1); }
     }
     // Retire the Q loads HERE: if they are still counted as pending at the loop header, hipcc's conservative
     // vmcnt bookkeeping waits for them in every iteration - behind the tile prefetch issued at the top of the
@@ -222,16 +219,13 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks].x), "v"(qf[ks].y), "v"(qf[ks].z), "v"(qf[ks].w));
     __syncthreads();
-    if (live(t0)) qk(t0 & 1, sc0, sc1);
-    __syncthreads();          // K[t0 & 1] is refilled at the end of the first iteration: every wave's S(t0) reads come first
     typedef uint32_t fl_u32x2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) const volatile fl_u32x2* fl_lds_cv64;     // volatile drops the inferred address space: say it
     for (int t = t0; t < t1; ++t) {
         const int buf = t & 1, kv0 = t * FL_BKV;
-        if (t + 2 < t1) load_k(t + 2);
-        if (t + 1 < t1) load_v(t + 1);
-        const bool cur = live(t), nxt = live(t + 1);
-        if (nxt) qk(buf ^ 1, sn0, sn1);
+        if (t + 1 < t1) { load_k(t + 1); load_v(t + 1); }
+        const bool cur = live(t);
+        if (cur) qk(buf, sc0, sc1);
         if (cur) {
             // ---- mask, online softmax (this lane: query qw0 + ql, kv rows (r&3) + 8(r>>2) + 4h of each sub-tile) ----
             const bool need_mask = kv0 + FL_BKV - 1 > causal_off + qw0 || kv0 + FL_BKV > kv_len;   // wave-uniform
@@ -300,10 +294,8 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
                 }
             }
         }
-        if (t + 2 < t1) store_k(buf);
-        if (t + 1 < t1) store_v(buf ^ 1);
+        if (t + 1 < t1) { store_k(buf ^ 1); store_v(buf ^ 1); }
         __syncthreads();
-        if (nxt) { sc0 = sn0; sc1 = sn1; }
     }
 
     // ---- normalise and store: lane = query row, registers 4g..4g+3 of tile i are d = 32i + 8g + 4h .. +3 ----

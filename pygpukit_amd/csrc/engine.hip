@@ -32,6 +32,8 @@
 
 namespace pgk {
 
+constexpr int SHORT_CTX = 512;   // contexts up to here take the whole-context attention kernels (fused o_proj / direct batch attention)
+
 pgk_status engine_gemm_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, void* C, bool accum_f32, int M,
                           int N, int K, hipStream_t st);
 int wsgemm_pick_splits(int N, int K, bool allow_split);
@@ -67,30 +69,6 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(unsigned long long* tl,
     // struct's s_load through a scalar cache the dispatch had just invalidated.
     static_assert(!(PRO == PRO_NORM_SUM && EPI == EPI_RESID), "aux_ cannot carry partial vectors and residual rows at once");
     const TLStamp tls(tl);
-    if constexpr (PRO == PRO_NORM && EPI == EPI_STORE && M <= 2) {
-        if (a.pf_k != nullptr && (int)blockIdx.x >= a.pf_first) {   // a prefetching workgroup (FusedArgs::pf_k): workgroup-uniform
-            __shared__ __attribute__((aligned(16))) char pf_sink[1024];
-            const int w = (int)blockIdx.x - a.pf_first;
-            const int s = w % a.pf_nsplit, hb = w / a.pf_nsplit, b = hb / a.pf_hkv;     // hb = kv head + Hkv x sequence
-            const int pos = load_uniform_i32(a.pf_pos + b);
-            const int r0 = s * a.pf_chunk, r1 = min(r0 + a.pf_chunk, min(pos, a.pf_max_seq));   // the slice's cached rows
-            const int nch = (r1 - r0) * a.pf_row16;
-            if (nch > 0) {
-                const size_t base = ((size_t)hb * a.pf_max_seq + r0) * a.pf_row16 * 8;        // elements
-                const uint32_t sink = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)pf_sink;
-                const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), ln = threadIdx.x & 63;
-                for (int j = wv; j * 64 < nch; j += 4) {
-                    const int idx = min(j * 64 + ln, nch - 1);
-                    // LDS-DMA into a sink: no destination registers to keep alive, nothing the compiler counts
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a.pf_k + base + (size_t)idx * 8), "s"(sink) : "memory", "m0");
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a.pf_v + base + (size_t)idx * 8), "s"(sink) : "memory", "m0");
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            tls.end();
-            return;
-        }
-    }
     constexpr int NW = WTraits<WT>::NW;
     constexpr bool FP8 = std::is_same<WT, fp8e4m3>::value;
     constexpr int KC = C * 64 * NW;           // compile-time K (0 = runtime)
@@ -104,9 +82,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(unsigned long long* tl,
     const int N = N_;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     constexpr int OUT_PER_TRIP = (EPI == EPI_SWIGLU) ? R / 2 : R;
-    int ncomp = gridDim.x;        // computing workgroups (the rest of the grid, if any, prefetches: see the top of the kernel)
-    if constexpr (PRO == PRO_NORM && EPI == EPI_STORE && M <= 2) { if (a.pf_k != nullptr) ncomp = a.pf_first; }
-    const int wave = blockIdx.x * 4 + wid, nwaves = ncomp * 4;
+    const int wave = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
 
     auto row_of = [&](int n0, int r) -> int {
         if constexpr (EPI == EPI_SWIGLU) return (r < R / 2) ? min(n0 + r, N - 1) : N + min(n0 + r - R / 2, N - 1);
@@ -1536,7 +1512,6 @@ struct Engine {
     bool batched_mfma = true;   // chunks of 3 and 5..16 sequences use engine_batched.hip.h (PGK_BATCHED_MFMA=0: GEMV kernels only, =2: from 3 up)
     int batched_min = 5, batched_max = 64;   // PGK_BATCHED_MAX=16: chunks of at most 16 sequences (one weight pass per chunk), the A/B switch of the tiled kernels
     int cu_count = 256;
-    bool kv_prefetch = true;    // long contexts, one or two sequences: the qkv launch also pulls the attention slices' K / V rows into L2 (PGK_KV_PREFETCH=0: off)
     bool short_path = true;     // contexts <= SHORT_CTX take the whole-context attention kernels (PGK_FUSED_ATTN=0: the split-KV sequence at every context)
     int pos_hi = -1;            // host-side upper bound of the largest position the next step sees (-1: unknown); selects the sequence, see step_is_short
     // in-graph stochastic sampling (pgk_engine_set_sampling): temperature <= 0 keeps greedy argmax
@@ -1613,16 +1588,10 @@ static pgk_status launch_fused_c(const FusedArgs& a, int n_out, hipStream_t st, 
     }
     int grid = force_grid ? force_grid : ceil_div(n_out, OUT_PER_TRIP * 4);
     if (grid > 1024) grid = 1024;
-    FusedArgs a2 = a;
-    if constexpr (PRO == PRO_NORM && EPI == EPI_STORE && M <= 2) {
-        if (a.pf_k != nullptr) { a2.pf_first = grid; grid += a.pf_n; }
-    } else {
-        a2.pf_k = nullptr;
-    }
     const float* x = (PRO == PRO_PLAIN) ? a.xin : a.h;
     const float* aux = (PRO == PRO_NORM_SUM) ? a.part : a.res;
     const int naux = (PRO == PRO_NORM_SUM) ? a.nsplit : a.ld_out;
-    PGK_CHECK_HIP(launch_k(kfn, dim3(grid), dim3(256), lds, st, a.w, a.wscale, x, a.gamma, aux, a.N, naux, a2));
+    PGK_CHECK_HIP(launch_k(kfn, dim3(grid), dim3(256), lds, st, a.w, a.wscale, x, a.gamma, aux, a.N, naux, a));
     return PGK_OK;
 }
 
@@ -1810,19 +1779,6 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
         a.w = L.w_qkv; a.wscale = (const bf16*)L.s_qkv; a.N = NQKV; a.K = H;
         a.h = h; a.gamma = (const bf16*)L.attn_norm; a.eps = c.norm_eps;
         a.out = e->qkv + (size_t)b0 * NQKV; a.ld_out = NQKV;
-        if constexpr (M <= 2) {
-            if (!fused && !direct && e->kv_prefetch) {
-                // split-KV attention next: prefetching workgroups ride on this launch (FusedArgs::pf_k); same slicing as launch_attn
-                const int gran = 4 * (64 / (D / 8));
-                int ns = e->cu_count / (c.num_kv_heads * M);
-                ns = ns < 1 ? 1 : (ns > e->nsplit ? e->nsplit : ns);
-                const int nsl = ceil_div(c.max_seq_len, decode_chunk_len(c.max_seq_len, ns, gran));
-                const size_t lofs = (size_t)l * e->kv_layer_elems() + (size_t)b0 * c.num_kv_heads * c.max_seq_len * D;
-                a.pf_k = e->kcache + lofs; a.pf_v = e->vcache + lofs; a.pf_pos = e->positions + b0;
-                a.pf_n = nsl * c.num_kv_heads * M; a.pf_nsplit = nsl; a.pf_hkv = c.num_kv_heads; a.pf_max_seq = c.max_seq_len;
-                a.pf_chunk = decode_chunk_len(c.max_seq_len, nsl, gran); a.pf_row16 = D / 8;
-            }
-        }
         if (pgk_status r = launch_fused_auto<WT, XT, M, PRO_NORM, EPI_STORE>(a, NQKV, st)) return r;
         mark(KC_ATTN);
         // 2. attention (QK-norm, RoPE, KV write fused; on the fused path also the o_proj partial products)
@@ -2079,8 +2035,6 @@ static pgk_status decode_chunk_packed(Engine* e, int b0, int M, bool last, hipSt
     return PGK_OK;
 }
 
-constexpr int SHORT_CTX = 512;   // contexts up to here take the whole-context attention kernels (fused o_proj / direct batch attention)
-
 template <class WT>
 static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* launches, bool short_ctx) {
     int b0 = 0;
@@ -2093,7 +2047,7 @@ static pgk_status decode_step_impl(Engine* e, int batch, hipStream_t st, int* la
         const bool mfma_ok = e->batched_mfma && (rem >= e->batched_min || (e->batched_min == 5 && rem == 3));
         if (mfma_ok) {
             const int m = rem > e->batched_max ? e->batched_max : rem;
-            if (m > 16 && e->packed_decode && !std::is_same<WT, fp8e4m3>::value) r = decode_chunk_packed(e, b0, m, rem == m, st, launches, short_ctx);
+            if (m > 16 && e->packed_decode) r = decode_chunk_packed(e, b0, m, rem == m, st, launches, short_ctx);
             else r = decode_chunk_batched<WT>(e, b0, m, rem == m, st, launches, short_ctx);
             b0 += m;
         }
@@ -2171,7 +2125,6 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         // PGK_FUSED_ATTN=0: no short-context launch sequence at all (the split-KV sequence at every context; A/B and tests)
         const char* env = getenv("PGK_FUSED_ATTN");
         e->short_path = env ? atoi(env) != 0 : true;
-        if (const char* kp = getenv("PGK_KV_PREFETCH")) e->kv_prefetch = atoi(kp) != 0;
         e->fused_attn = tiles && c.weight_format == 0 && (G == 1 || G == 2 || G == 4);
         e->oproj_rows = rows;
         {
@@ -2240,7 +2193,9 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         size_t free_b = 0, total_b = 0;
         const bool fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && per_layer * c.num_layers < free_b / 4;
         const bool shapes = pkgemm_shape_ok(NQ, H, false) && pkgemm_shape_ok(H, QDp, true) && pkgemm_shape_ok(2 * I, H, false) && pkgemm_shape_ok(H, I, true) && I % 64 == 0;
-        if (r == PGK_OK && c.weight_format == 0 && shapes && fits && !(ep && atoi(ep) == 0)) {
+        // bf16 layers, or fp8 codes + block scales (w8a16): the copy is bf16 either way (ops_pkgemm.hip)
+        const bool f8w = c.weight_format == 1;
+        if (r == PGK_OK && (c.weight_format == 0 || f8w) && shapes && fits && !(ep && atoi(ep) == 0)) {
             e->packed.resize(c.num_layers);
             hipStream_t st = resolve_stream(nullptr);
             for (int l = 0; l < c.num_layers && r == PGK_OK; ++l) {
@@ -2250,10 +2205,10 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
                 A((void**)&P.o, (size_t)H * QDp * 2, &e->packed_bytes);
                 A((void**)&P.gate_up, (size_t)2 * I * H * 2, &e->packed_bytes);
                 A((void**)&P.down, (size_t)H * I * 2, &e->packed_bytes);
-                if (r == PGK_OK) r = pack_weights_bf16(L.w_qkv, P.qkv, NQ, H, st);
-                if (r == PGK_OK) r = pack_weights_bf16(L.w_o, P.o, H, QDp, st);
-                if (r == PGK_OK) r = pack_weights_bf16(L.w_gate_up, P.gate_up, 2 * I, H, st);
-                if (r == PGK_OK) r = pack_weights_bf16(L.w_down, P.down, H, I, st);
+                if (r == PGK_OK) r = f8w ? pack_weights_fp8(L.w_qkv, L.s_qkv, P.qkv, NQ, H, st) : pack_weights_bf16(L.w_qkv, P.qkv, NQ, H, st);
+                if (r == PGK_OK) r = f8w ? pack_weights_fp8(L.w_o, L.s_o, P.o, H, QDp, st) : pack_weights_bf16(L.w_o, P.o, H, QDp, st);
+                if (r == PGK_OK) r = f8w ? pack_weights_fp8(L.w_gate_up, L.s_gate_up, P.gate_up, 2 * I, H, st) : pack_weights_bf16(L.w_gate_up, P.gate_up, 2 * I, H, st);
+                if (r == PGK_OK) r = f8w ? pack_weights_fp8(L.w_down, L.s_down, P.down, H, I, st) : pack_weights_bf16(L.w_down, P.down, H, I, st);
             }
             if (r == PGK_OK && hipStreamSynchronize(st) != hipSuccess) r = set_error(PGK_ERR_HIP, "pgk_engine_create: packing the prefill weights failed");
             e->packed_ok = r == PGK_OK;

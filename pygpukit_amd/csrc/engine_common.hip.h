@@ -126,16 +126,6 @@ struct FusedArgs {
     int* amax_idx;
     // batched MFMA path only: bf16 hand-off between projections (the consumer rounds to bf16 anyway, so the producer
     // does it once and every consuming workgroup reads half the bytes)
-    // Long-context decode (one or two sequences, split-KV attention next): the qkv launch carries pf_n extra workgroups behind
-    // its pf_first computing ones whose only job is to pull the cached K / V rows of the attention slices into L2 - extra
-    // workgroup w touches exactly what workgroup w of the slice kernel will read, and both have the same id mod 8, i.e. the
-    // same XCD and L2 (placement is a speed matter only).  The slice kernel otherwise starts with one cold HBM round trip for
-    // 41 KB per workgroup (profiles/r02_config3_timeline.json); here that trip runs beside the qkv GEMV, whose fp8 weight
-    // stream leaves HBM bandwidth to spare.
-    const bf16 *pf_k, *pf_v;      // this layer's caches [B][Hkv][max_seq][D]; null: no prefetch workgroups
-    const int32_t* pf_pos;        // positions[B]
-    int pf_first, pf_n;           // computing workgroups, prefetching workgroups
-    int pf_nsplit, pf_hkv, pf_max_seq, pf_chunk, pf_row16;   // slices per head, kv heads, cache rows, rows per slice, 16-byte chunks per row
     const bf16* xin16;    // PRO_PLAIN: [M][K] bf16, used instead of xin when set
     bf16* out16;          // EPI_SWIGLU: [M][ld_out] bf16, written instead of out when set
 };

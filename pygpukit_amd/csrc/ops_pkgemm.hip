@@ -66,6 +66,38 @@ pgk_status pack_weights_bf16(const void* w, void* wp, int N, int K, hipStream_t 
     return PGK_OK;
 }
 
+// fp8-weight (w8a16) engines get the SAME bf16 fragment-major working copy, dequantised once at engine creation:
+// wp = bf16(lut[code] * block scale), the value the reference's w8a16 GEMM puts in front of its MMA
+// (native/ops/matmul/gemm/w8a16_bf16/sm120/w8a16_gemm.cu:187-203) and the M > 1 kernels of engine_batched.hip.h form on the
+// fly.  The batch-1 GEMV - what BASELINE config 3 measures - still streams the one-byte codes; the skinny-GEMM paths
+// (prompts of <= 128 tokens, decode steps of 17-64 sequences) are latency- and texture-addresser-bound, not byte-bound,
+// so they take the kernels above unchanged (fp8 batch 64: 1.77 ms per step on the row-major kernels).
+__global__ void pack_weights_fp8_kernel(const uint8_t* w, const bf16* scale, bf16* wp, int N, int K) {
+    const size_t chunks = (size_t)N * K / 8, stride = (size_t)gridDim.x * blockDim.x;
+    const int ksn = K / 32, KB = K >> 7;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < chunks; t += stride) {
+        const int l = (int)(t & 63);
+        const size_t blk = t >> 6;
+        const int ks = (int)(blk % ksn), nt = (int)(blk / ksn);
+        const int row = nt * 16 + (l & 15), k = ks * 32 + 8 * (l >> 4);
+        const uint2 v = *reinterpret_cast<const uint2*>(w + (size_t)row * K + k);
+        const float sc = to_f(scale[(size_t)(row >> 7) * KB + (k >> 7)]);
+        const f32x2 c0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, false), c1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, true);
+        const f32x2 c2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, false), c3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, true);
+        *reinterpret_cast<uint4*>(wp + t * 8) = make_uint4(pack_bf16x2(c0.x * sc, c0.y * sc), pack_bf16x2(c1.x * sc, c1.y * sc),
+                                                          pack_bf16x2(c2.x * sc, c2.y * sc), pack_bf16x2(c3.x * sc, c3.y * sc));
+    }
+}
+
+pgk_status pack_weights_fp8(const void* w, const void* scale, void* wp, int N, int K, hipStream_t st) {
+    PGK_REQUIRE(N % 16 == 0 && K % 128 == 0 && scale != nullptr, "pack_weights_fp8: N=%d must be a multiple of 16, K=%d of 128, scales present", N, K);
+    const size_t chunks = (size_t)N * K / 8;
+    const int grid = (int)(chunks / 256 > 4096 ? 4096 : (chunks + 255) / 256);
+    pack_weights_fp8_kernel<<<grid, 256, 0, st>>>((const uint8_t*)w, (const bf16*)scale, (bf16*)wp, N, K);
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
+}
+
 #ifdef PGK_PHASE_STAMPS
 // diagnostic build only (tools/pk_stamps.py): 100 MHz stamps of workgroup phases, last launch of each epilogue kind
 __device__ unsigned long long g_pk_stamps[5][512][8];

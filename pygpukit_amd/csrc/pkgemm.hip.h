@@ -36,6 +36,8 @@ struct PkArgs {
 constexpr int PK_SS_LD = 64;    // floats per row of a sum-of-squares table
 
 pgk_status pack_weights_bf16(const void* w, void* wp, int N, int K, hipStream_t st);
+// the same working copy for fp8 (e4m3) weights with 128 x 128 bf16 block scales: wp = bf16(code * scale), fragment-major
+pgk_status pack_weights_fp8(const void* w, const void* scale, void* wp, int N, int K, hipStream_t st);
 int pkgemm_pick_splits(int M, int N, int K);
 bool pkgemm_shape_ok(int N, int K, bool splittable);
 // h[M][N] += A[M][K] . W^T (no K split over workgroups: the K quarters of a workgroup's waves meet in LDS), and for the next

@@ -1,6 +1,6 @@
 """A/B the staggered vs lockstep 256x256 bf16 GEMM inside the Llama-8B-shape bf16 prefill, interleaved in one process."""
 import os, sys, time, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from pygpukit_amd.llm import synthetic as S
 from pygpukit_amd.llm.engine import Engine
 L, n = 8, 4096

@@ -3,7 +3,7 @@ Reports prefill time and TFLOP/s (projection GEMM FLOPs + causal attention, last
 fp8 x fp8 path ("fp8a8"), the w8a16 path ("fp8") and bf16, and the last-row logits differences between them.
 usage: config5_prefill.py [S=4096] [layers=32] [reps=3]"""
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from pygpukit_amd.llm import synthetic as S
 from pygpukit_amd.llm.engine import Engine
 

@@ -1,6 +1,6 @@
 """Error budget of the fp8-activation prefill (weight_format fp8a8) on a Llama-style mini model."""
 import sys, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from oracle import cpu_ref as O
 from pygpukit_amd.llm import synthetic as S
 from tests.conftest import rel_err

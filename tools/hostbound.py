@@ -1,5 +1,5 @@
 import time, numpy as np, sys
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from pygpukit_amd.llm import synthetic as S
 from pygpukit_amd import _hip
 cfg=dict(S.QWEN3_0_6B)

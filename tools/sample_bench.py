@@ -1,6 +1,6 @@
 """Time pgk_sample_token on one fp32 logits row of Qwen3's vocabulary."""
 import ctypes as C, sys, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from pygpukit_amd import _hip
 _hip.require_device()
 V = 151936

@@ -2,7 +2,7 @@
 draws (the sampler's launches are nodes of the step graph; uniforms come from the device ring).
 usage: sampled_decode.py [steps=64]"""
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from pygpukit_amd.llm import synthetic as S
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 cfg = dict(S.QWEN3_0_6B)

@@ -2,7 +2,7 @@
 prefill) against the CPU oracle.  Validates the K = 4096 / 14336 GEMM paths end to end and shows how much of the
 fp8-vs-bf16 gap at this width is the quantisation itself (oracle vs oracle)."""
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from oracle import cpu_ref as O
 from pygpukit_amd.llm import synthetic as S
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 2

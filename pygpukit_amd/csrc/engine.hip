@@ -42,6 +42,11 @@ pgk_status engine_gemm_nt_slabs(const bf16* A, const void* W, float* slabs, int 
 pgk_status gemm_fp8_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, void* c, bool accum_f32, int M,
                        int N, int K, hipStream_t st);
 pgk_status quantize_fp8_rows_bf16(const bf16* x, uint8_t* out, float* scale, int M, int K, hipStream_t st);
+bool engine_gemm_swiglu_ok(int M, int I, int K, bool fp8);     // ops_gemm.hip: gate / up projection with the SwiGLU epilogue
+pgk_status engine_gemm_swiglu_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, bf16* act, int M, int I, int K, hipStream_t st);
+bool gemm_fp8_swiglu_ok(int M, int I, int K);                  // ops_fp8_gemm.hip: ... and the e4m3 quantisation of the result
+pgk_status gemm_fp8_swiglu_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, uint8_t* q_out, float* s_out, int M, int I,
+                              int K, hipStream_t st);
 pgk_status wsgemm_nt(const bf16* a, int lda, const void* w, const bf16* wscale, bool fp8, void* c, const bf16* bias, int mode,
                      int splits, int M, int N, int K, hipStream_t st);
 
@@ -2317,7 +2322,7 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     if (s_qkv > 1 && (size_t)s_qkv * n * NQKV > slab_elems) slab_elems = (size_t)s_qkv * n * NQKV;
     if (s_gu > 1 && (size_t)s_gu * n * 2 * I > slab_elems) slab_elems = (size_t)s_gu * n * 2 * I;
     const size_t need = (size_t)n * H * 4 + ((size_t)n * H + (size_t)n * NQKV + (size_t)n * QD + (size_t)n * 2 * I + (size_t)n * I) * 2 +
-                        (use_slabs ? slab_elems * 4 : 0) + 512 + (c.weight_format == 2 ? (size_t)n * maxk + (size_t)n * (maxk / 128) * 4 + 512 : 0);
+                        (use_slabs ? slab_elems * 4 : 0) + 512 + (c.weight_format == 2 ? 2 * ((size_t)n * maxk + (size_t)n * (maxk / 128) * 4 + 512) : 0);
     if (need > e->pf_bytes) {
         if (e->pf) PGK_CHECK_HIP(hipStreamSynchronize(st));
         if (e->pf) pgk_free(e->pf);
@@ -2346,12 +2351,18 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     float* slabs = (float*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
     uint8_t* q8 = (uint8_t*)(((uintptr_t)slabs + (use_slabs ? slab_elems * 4 : 0) + 255) & ~(uintptr_t)255);   // fp8 activations [n][maxk]
     float* q8s = (float*)(q8 + (size_t)n * maxk);                                                          // their scales [n][maxk/128]
+    uint8_t* q8b = (uint8_t*)(((uintptr_t)(q8s + (size_t)n * (maxk / 128)) + 255) & ~(uintptr_t)255);      // second pair: the gate / up GEMM's
+    float* q8bs = (float*)(q8b + (size_t)n * maxk);                                                        // SwiGLU epilogue writes while q8 is its operand
     int pending = 0;   // split-K slabs of the previous projection still to be added into h32 by the next norm
     // fp8act: RMSNorm and SwiGLU leave their result in q8/q8s themselves (x_in == nullptr); attention output is
     // quantised here (its rows span all heads, a flash workgroup only sees one)
-    // (PGK_FP8_FUSED_QUANT=0 keeps the separate quantise pass: the A/B switch of the bit-identity test)
-    const char* fq_env = getenv("PGK_FP8_FUSED_QUANT");
-    const bool fuse_q = fp8act && H % 128 == 0 && I % 128 == 0 && H <= 4096 && !(fq_env && atoi(fq_env) == 0);
+    // (PGK_FUSED_EPILOGUES=0 keeps the separate passes - quantise, SwiGLU: the A/B switch of the bit-identity tests)
+    const char* fq_env = getenv("PGK_FUSED_EPILOGUES");
+    const bool fuse_epi = !(fq_env && atoi(fq_env) == 0);
+    const bool fuse_q = fp8act && H % 128 == 0 && I % 128 == 0 && H <= 4096 && fuse_epi;
+    // SwiGLU in the gate / up GEMM's epilogue (256-tile kernels; fp8 x fp8: with the quantisation of its result)
+    const bool fuse_sw8 = fuse_q && gemm_fp8_swiglu_ok(n, I, H);
+    const bool fuse_sw16 = !fp8act && !ws && fuse_epi && engine_gemm_swiglu_ok(n, I, H, fp8);
     auto proj_accum = [&](const bf16* x_in, const void* w, const void* sc, int N_, int K_, int splits) -> pgk_status {
         if (fp8act) {
             if (x_in)
@@ -2457,6 +2468,17 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
             // SwiGLU inside the gate_up projection: the gate tile and its up tile live in the same wave
             if (pgk_status r = pkgemm_nt(x, H, e->packed[l].gate_up, act, I, PK_EPI_SWIGLU, 1, n, 2 * I, H, nullptr, st)) return r;
             if (pgk_status r = pk_accum(act, e->packed[l].down, I, pk_sd)) return r;
+            continue;
+        }
+        if (fuse_sw8) {
+            // x's codes in q8 -> act's codes in q8b; the down projection reads q8b
+            if (pgk_status r = gemm_fp8_swiglu_nt(q8, q8s, (const uint8_t*)L.w_gate_up, (const bf16*)L.s_gate_up, q8b, q8bs, n, I, H, st)) return r;
+            if (pgk_status r = gemm_fp8_nt(q8b, q8bs, (const uint8_t*)L.w_down, (const bf16*)L.s_down, h32, true, n, H, I, st)) return r;
+            continue;
+        }
+        if (fuse_sw16) {
+            if (pgk_status r = engine_gemm_swiglu_nt(x, L.w_gate_up, (const bf16*)L.s_gate_up, fp8, act, n, I, H, st)) return r;
+            if (pgk_status r = proj_accum(act, L.w_down, L.s_down, H, I, s_d)) return r;
             continue;
         }
         if (pgk_status r = proj_store(fuse_q ? nullptr : x, L.w_gate_up, L.s_gate_up, gu, 2 * I, H, s_gu)) return r;

@@ -209,7 +209,17 @@ __global__ __launch_bounds__(256) void quantize_blocks_kernel(const bf16* w, uin
 
 pgk_status gemm256_fp8_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, void* c, bool accum_f32, int M, int N,
                           int K, hipStream_t st);
+pgk_status gemm256_fp8_swiglu_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, uint8_t* q_out, float* s_out, int M,
+                                 int I, int K, hipStream_t st);
 bool want_gemm256(int M, int N);      // ops_gemm.hip
+
+// gate / up projection with the SwiGLU + e4m3 quantisation epilogue (ops_gemm256.hip): whole 256-row tiles, enough of them
+bool gemm_fp8_swiglu_ok(int M, int I, int K) { return K % 128 == 0 && I % 128 == 0 && M % 256 == 0 && want_gemm256(M, 2 * I); }
+pgk_status gemm_fp8_swiglu_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, uint8_t* q_out, float* s_out, int M, int I,
+                              int K, hipStream_t st) {
+    PGK_REQUIRE(gemm_fp8_swiglu_ok(M, I, K), "gemm_fp8_swiglu: M=%d I=%d K=%d outside the fused kernel's shapes", M, I, K);
+    return gemm256_fp8_swiglu_nt(a, sa, w, sw, q_out, s_out, M, I, K, st);
+}
 
 // internal entry used by the engine's fp8-activation prefill
 pgk_status gemm_fp8_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, void* c, bool accum_f32, int M,

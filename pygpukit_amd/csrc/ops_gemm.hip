@@ -21,6 +21,7 @@ pgk_status wsgemm_nt(const bf16* a, int lda, const void* w, const bf16* wscale, 
                      int splits, int M, int N, int K, hipStream_t st);
 pgk_status gemm256_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, bool accum_f32, int M, int N, int K,
                            hipStream_t st);
+pgk_status gemm256_bf16_swiglu_nt(const bf16* A, const bf16* W, bf16* act, int M, int I, int K, hipStream_t st);
 // the 256 x 256 structure needs enough tiles to fill the chip and whole 128-byte K rows
 // PGK_GEMM256 = 0 / 1 forces the choice (read per call: tests flip it to drive small shapes through both kernels); shared
 // with the fp8 x fp8 GEMM (ops_fp8_gemm.hip)
@@ -419,6 +420,23 @@ pgk_status engine_gemm_nt(const bf16* A, const void* W, const bf16* wscale, bool
     if (use_gemm256(M, N, K)) return gemm256_bf16_nt(A, (const bf16*)W, nullptr, C, accum_f32, M, N, K, st);
     if (accum_f32) return dispatch_mfma<bf16, B_NT, 1>(A, W, nullptr, nullptr, C, M, N, K, st);
     return dispatch_mfma<bf16, B_NT, 0>(A, W, nullptr, nullptr, C, M, N, K, st);
+}
+
+// internal (engine prefill): act[M][I] = bf16(silu(A . Wg^T) * (A . Wu^T)) on the fused [2 I, K] gate / up weight (bf16, or fp8 with
+// block scales: dequantised once into a bf16 scratch as in engine_gemm_nt), SwiGLU in the 256-tile kernel's epilogue - the
+// [M][2 I] intermediate never goes to HBM.  Only where engine_gemm_nt would pick the 256-tile kernel anyway.
+bool engine_gemm_swiglu_ok(int M, int I, int K, bool fp8) { return I % 128 == 0 && use_gemm256(M, 2 * I, K) && (!fp8 || K % 128 == 0); }
+pgk_status engine_gemm_swiglu_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, bf16* act, int M, int I, int K, hipStream_t st) {
+    PGK_REQUIRE(engine_gemm_swiglu_ok(M, I, K, fp8), "engine_gemm_swiglu: M=%d I=%d K=%d outside the fused kernel's shapes", M, I, K);
+    if (!fp8) return gemm256_bf16_swiglu_nt(A, (const bf16*)W, act, M, I, K, st);
+    void* wb = nullptr;
+    if (pgk_status r = pgk_malloc(&wb, (size_t)2 * I * K * sizeof(bf16))) return r;
+    const size_t chunks = (size_t)2 * I * K / 16;
+    dequant_fp8_blocks_kernel<<<(unsigned)(ceil_div((long long)chunks, 256) > 8192 ? 8192 : ceil_div((long long)chunks, 256)), 256, 0, st>>>(
+        (const uint8_t*)W, wscale, (bf16*)wb, 2 * I, K);
+    const pgk_status r = gemm256_bf16_swiglu_nt(A, (const bf16*)wb, act, M, I, K, st);
+    pgk_free(wb);   // stream-ordered reuse
+    return r;
 }
 
 }  // namespace pgk

@@ -62,6 +62,64 @@ __device__ __forceinline__ void g2_tile_of(int id, int nwg, int ntm, int ntn, in
     tn = in / gsz;
 }
 
+// ---- SwiGLU epilogue (EPI 2 of the kernels below): W is the fused [2 I, K] gate / up weight, the workgroup's 256 B-tile rows are
+// gate rows [128 tn, +128) followed by up rows [I + 128 tn, +128), so output tile tn holds act columns [128 tn, +128): waves
+// wc 0 / 1 hold gate columns, wc 2 / 3 the matching up columns.  The accumulators go to LDS as the bf16 tile the plain kernel
+// would have stored ([256][256] bf16 = the 128 KiB the operand stages occupied; 2-byte writes, the 32-byte run of a lane
+// quarter XOR-ed by q so the four quarters of a wave hit different banks), then 16 consecutive lanes take one row's 128
+// act columns, 8 each: act = bf16(silu(g) * u) from the bf16-ROUNDED g and u - the arithmetic of swiglu_rows_kernel
+// (engine.hip) on the values the plain epilogue stores, so the result is bit-identical to GEMM + swiglu_rows_kernel - and
+// store 16 bytes of bf16, or (QOUT) 8 e4m3 codes with the row's scale for this 128-column block (absmax / 448 over the 16
+// lanes, quantize_fp8_rows' contract): exactly the fp8 x fp8 down projection's A operand.  Saves the [M][2 I] bf16 round
+// trip through HBM (Llama-3-8B shape, S = 4096: 235 MB written + read back = ~75 us of a 1.4 ms layer) and a launch.
+template <bool QOUT>
+__device__ __forceinline__ void g2_swiglu_epilogue(char* smem, const f32x4_g (&acc)[8][4], int tid, int m0, int tn, int M, int I,
+                                                   void* outv, float* out_scales) {
+    const int lane = tid & 63, wid = tid >> 6, wr = wid >> 2, wc = wid & 3, q = lane >> 4, l15 = lane & 15;
+    __builtin_amdgcn_s_barrier();                    // every wave is past its last operand read (DMAs retired by the caller)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr * 128 + i * 16 + q * 4 + r, colb = (wc * 64 + j * 16 + l15) * 2;
+                *reinterpret_cast<bf16*>(smem + row * 512 + (colb ^ (q << 5))) = from_f<bf16>(acc[i][j][r]);   // (row >> 2) & 3 == q
+            }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int item = it * G2_THREADS + tid, row = item >> 4, c = item & 15, sw = ((row >> 2) & 3) << 5;
+        Vec<bf16> g, u;
+        g.raw = *reinterpret_cast<const uint4*>(smem + row * 512 + ((c * 16) ^ sw));
+        u.raw = *reinterpret_cast<const uint4*>(smem + row * 512 + ((256 + c * 16) ^ sw));
+        float gf[8], uf[8];
+        g.to_float(gf);
+        u.to_float(uf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gf[e] = gf[e] / (1.0f + __expf(-gf[e])) * uf[e];
+        g.from_float(gf);
+        const size_t grow = (size_t)m0 + row;
+        if constexpr (QOUT) {
+            g.to_float(gf);
+            float amax = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(gf[e]));
+            amax = group16_max(amax);
+            const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+            uint2 o;
+            o.x = pack_fp8x4(gf[0] / sc, gf[1] / sc, gf[2] / sc, gf[3] / sc);
+            o.y = pack_fp8x4(gf[4] / sc, gf[5] / sc, gf[6] / sc, gf[7] / sc);
+            if (grow < (size_t)M) {
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(outv) + grow * I + tn * 128 + c * 8) = o;
+                if (c == 0) out_scales[grow * (I >> 7) + tn] = sc;
+            }
+        } else {
+            if (grow < (size_t)M) g.store(reinterpret_cast<bf16*>(outv) + grow * I + tn * 128 + c * 8);
+        }
+    }
+}
+
 template <int EPI>   // 0: bf16 C store (+bias); 1: fp32 C +=
 __global__ __launch_bounds__(G2_THREADS) void gemm256_bf16_kernel(const bf16* A, const bf16* W, const bf16* bias, void* Cv,
                                                                    int M, int N, int K, int ntm, int ntn) {
@@ -181,7 +239,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_bf16_kernel(const bf16* A,
 // lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32), not in runs of 16 lanes: the first version's swizzle
 // (r >> 2) & 3 was conflict-free for runs of 16 and 2-way conflicted for the real groups (SQ_LDS_BANK_CONFLICT = half of
 // SQ_LDS_IDX_ACTIVE, profiles/r03_gemm_pmc.txt); (r >> 2) & 2 is conflict-free for them (exhaustive check).
-template <int EPI>
+template <int EPI>   // 0: bf16 C store (+bias); 1: fp32 C +=; 2: SwiGLU (W = fused gate / up rows, N = I act columns, C = bf16 act [M][I])
 __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A, const bf16* W, const bf16* bias, void* Cv,
                                                                     int M, int N, int K, int ntm, int ntn) {
     extern __shared__ __attribute__((aligned(16))) char g2_smem[];   // 4 stages x (A 16 KiB | W 16 KiB)
@@ -197,8 +255,11 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A
     const int dchunk = (lane & 3) ^ ((lane >> 4) & 2);      // = (lane & 3) ^ g2s_sw(row & 15), row & 15 = lane >> 2
     const bf16* a_src0 = A + (size_t)min(m0 + drow, M - 1) * K + dchunk * 8;
     const bf16* a_src1 = A + (size_t)min(m0 + drow + 16, M - 1) * K + dchunk * 8;
-    const bf16* w_src0 = W + (size_t)min(n0 + drow, N - 1) * K + dchunk * 8;
-    const bf16* w_src1 = W + (size_t)min(n0 + drow + 16, N - 1) * K + dchunk * 8;
+    // B-tile row r of an EPI-2 workgroup: gate row 128 tn + r for r < 128, up row N + 128 tn + (r - 128) after that (N = I)
+    const int wrow = (EPI == 2) ? (drow < 128 ? tn * 128 + drow : N + tn * 128 + drow - 128) : n0 + drow;
+    const int wlast = (EPI == 2) ? 2 * N - 1 : N - 1;
+    const bf16* w_src0 = W + (size_t)min(wrow, wlast) * K + dchunk * 8;
+    const bf16* w_src1 = W + (size_t)min(wrow + 16, wlast) * K + dchunk * 8;
     const uint32_t lds0 = g2_lds_addr(g2_smem);
     const int nh = K / 32;
     auto stage = [&](int h, int buf) {
@@ -259,6 +320,10 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A
     if (!late) __builtin_amdgcn_s_barrier();                 // match the extra barrier of waves 4-7
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // retire the phantom DMAs before the LDS is given back
 
+    if constexpr (EPI == 2) {
+        g2_swiglu_epilogue<false>(g2_smem, acc, tid, m0, tn, M, N, Cv, nullptr);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = n0 + wc * 64 + j * 16 + l15;
@@ -298,9 +363,9 @@ __device__ __forceinline__ void g2_dma2_so(const void* sbase, uint32_t voff, uin
 
 constexpr int G2_SCALE_BYTES = 256 * 4 + 256;   // per buffer: 256 fp32 row scales | 64 lanes x 4 B of weight-scale slots (2 used)
 
-template <int EPI>   // 0: bf16 C store; 1: fp32 C +=
+template <int EPI>   // 0: bf16 C store; 1: fp32 C +=; 2: SwiGLU + e4m3 quantisation (W = fused gate / up rows, N = I; Cv = codes [M][I], Cs = scales [M][I/128])
 __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* A, const float* sa, const uint8_t* W, const bf16* sw,
-                                                                  void* Cv, int M, int N, int K, int ntm, int ntn) {
+                                                                  void* Cv, float* Cs, int M, int N, int K, int ntm, int ntn) {
     extern __shared__ __attribute__((aligned(16))) char g2_smem[];   // A[2] | W[2] | scales[2]
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // in an SGPR: it enters the DMAs' scalar bases
     const int wr = wid >> 2, wc = wid & 3, q = lane >> 4, l15 = lane & 15;
@@ -327,9 +392,12 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
     // The per-lane offsets are RECOMPUTED from the lane id at every stage (a handful of vector instructions per tile): held
     // across the loop they are spilled at its fullest point, and every reload waits on the vector-memory counter.
     const uint8_t* a_tile = A + ((size_t)m0 + wid * 32) * K;
-    const uint8_t* w_tile = W + ((size_t)n0 + wid * 32) * K;
+    // EPI 2: B-tile rows 0-127 = gate rows 128 tn .., rows 128-255 = up rows N + 128 tn .. (N = I): waves 0-3 stage gate rows, 4-7 up rows,
+    // and the tile's two weight-scale blocks are block rows tn and I / 128 + tn
+    const uint8_t* w_tile = W + (size_t)((EPI == 2) ? (wid < 4 ? tn * 128 + wid * 32 : N + tn * 128 + (wid - 4) * 32) : n0 + wid * 32) * K;
     const float* sa_tile = sa + ((size_t)m0 + (wid & 3) * 64) * KB;      // waves 0-3: 64 row scales each (one per lane)
-    const bf16* sw_tile = sw + (size_t)(2 * tn) * KB;                     // wave 4: the tile's two weight-block scales (lanes 0 / 1)
+    const bf16* sw_tile = sw + (size_t)((EPI == 2) ? tn : 2 * tn) * KB;  // wave 4: the tile's two weight-block scales (lanes 0 / 1)
+    const uint32_t sw_step = (uint32_t)((EPI == 2) ? (N >> 7) : 1) * (uint32_t)(KB * 2);   // bytes between the two
     const uint32_t lds0 = g2_lds_addr(g2_smem);
     // operand tiles of K tile kt -> stage buf, as eight 1-KiB pieces (piece p: rows 8 (p >> 1) .. + 8 of this wave's 32, A for
     // even p, W for odd p).  Branch-free: the pieces are issued from the middle of the MFMA pipeline, one behind each MFMA of
@@ -358,7 +426,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
     auto stage_scales = [&](int kt, int buf) {
         const uint32_t s_dst = __builtin_amdgcn_readfirstlane(lds0 + 4 * G2_TILE + buf * G2_SCALE_BYTES + (wid < 4 ? wid * 256 : 1024));
         if (wid < 4) g2_dma4_so(sa_tile + kt, (uint32_t)lane * (uint32_t)(KB * 4), s_dst);
-        else if (wid == 4) g2_dma2_so(sw_tile + kt, ((uint32_t)lane & 1u) * (uint32_t)(KB * 2), s_dst);
+        else if (wid == 4) g2_dma2_so(sw_tile + kt, ((uint32_t)lane & 1u) * sw_step, s_dst);
     };
 
     f32x4_g acc[8][4];
@@ -482,6 +550,10 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
 #undef G2F_J
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // retire the phantom DMAs before the LDS is given back
 
+    if constexpr (EPI == 2) {
+        g2_swiglu_epilogue<true>(g2_smem, acc, tid, m0, tn, M, N, Cv, Cs);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = n0 + wc * 64 + j * 16 + l15;
@@ -509,8 +581,25 @@ pgk_status gemm256_fp8_nt(const uint8_t* a, const float* sa, const uint8_t* w, c
         attr_done = true;
     }
     const int ntm = ceil_div(M, G2_BM), ntn = ceil_div(N, G2_BN);
-    if (accum_f32) gemm256_fp8_kernel<1><<<ntm * ntn, G2_THREADS, LDS, st>>>(a, sa, w, sw, c, M, N, K, ntm, ntn);
-    else gemm256_fp8_kernel<0><<<ntm * ntn, G2_THREADS, LDS, st>>>(a, sa, w, sw, c, M, N, K, ntm, ntn);
+    if (accum_f32) gemm256_fp8_kernel<1><<<ntm * ntn, G2_THREADS, LDS, st>>>(a, sa, w, sw, c, nullptr, M, N, K, ntm, ntn);
+    else gemm256_fp8_kernel<0><<<ntm * ntn, G2_THREADS, LDS, st>>>(a, sa, w, sw, c, nullptr, M, N, K, ntm, ntn);
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
+}
+
+// act codes / scales = quantise(silu(a . Wg^T) * (a . Wu^T)), w = fused [2 I, K] gate / up codes with [2 I / 128][K / 128] block scales
+pgk_status gemm256_fp8_swiglu_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, uint8_t* q_out, float* s_out, int M,
+                                 int I, int K, hipStream_t st) {
+    PGK_REQUIRE(K % 128 == 0 && K >= 128 && M % G2_BM == 0 && I % 128 == 0, "gemm256 fp8 swiglu: M=%d must be a multiple of 256, I=%d and K=%d of 128", M, I, K);
+    PGK_REQUIRE((const void*)a != (const void*)q_out, "gemm256 fp8 swiglu: output aliases the activation operand");
+    constexpr size_t LDS = 4 * (size_t)G2_TILE + 2 * G2_SCALE_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_fp8_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        attr_done = true;
+    }
+    const int ntm = M / G2_BM, ntn = I / 128;
+    gemm256_fp8_kernel<2><<<ntm * ntn, G2_THREADS, LDS, st>>>(a, sa, w, sw, q_out, s_out, M, I, K, ntm, ntn);
     PGK_CHECK_HIP(hipGetLastError());
     return PGK_OK;
 }
@@ -542,6 +631,21 @@ pgk_status gemm256_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void*
     }
     if (accum_f32) gemm256_bf16_kernel<1><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn);
     else gemm256_bf16_kernel<0><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn);
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
+}
+
+// act[M][I] = bf16(silu(A . Wg^T) * (A . Wu^T)), W = fused [2 I, K] gate / up weight (staggered kernel, SwiGLU epilogue)
+pgk_status gemm256_bf16_swiglu_nt(const bf16* A, const bf16* W, bf16* act, int M, int I, int K, hipStream_t st) {
+    PGK_REQUIRE(K % 64 == 0 && K >= 64 && I % 128 == 0, "gemm256 swiglu: K=%d must be a multiple of 64 and I=%d of 128", K, I);
+    constexpr size_t LDS = 4 * (size_t)G2_TILE;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        attr_done = true;
+    }
+    const int ntm = ceil_div(M, G2_BM), ntn = I / 128;
+    gemm256s_bf16_kernel<2><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, nullptr, act, M, I, K, ntm, ntn);
     PGK_CHECK_HIP(hipGetLastError());
     return PGK_OK;
 }

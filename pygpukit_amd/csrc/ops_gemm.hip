@@ -22,6 +22,8 @@ pgk_status wsgemm_nt(const bf16* a, int lda, const void* w, const bf16* wscale, 
 pgk_status gemm256_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, bool accum_f32, int M, int N, int K,
                            hipStream_t st);
 pgk_status gemm256_bf16_swiglu_nt(const bf16* A, const bf16* W, bf16* act, int M, int I, int K, hipStream_t st);
+bool gemm128s_ok(int M, int N, int K);    // ops_gemm256.hip: 128 x 128 tiles on the staged LDS-DMA pipeline (bf16, M > 128, K % 64 == 0, N % 8 == 0)
+pgk_status gemm128s_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, int mode, int splits, int M, int N, int K, hipStream_t st);
 // the 256 x 256 structure needs enough tiles to fill the chip and whole 128-byte K rows
 // PGK_GEMM256 = 0 / 1 forces the choice (read per call: tests flip it to drive small shapes through both kernels); shared
 // with the fp8 x fp8 GEMM (ops_fp8_gemm.hip)
@@ -387,13 +389,14 @@ __global__ __launch_bounds__(256) void dequant_fp8_blocks_kernel(const uint8_t* 
 int engine_gemm_pick_splits(int M, int N, int K) {
     const long long tiles = (long long)ceil_div(M, 128) * ceil_div(N, 128);
     if (M <= 128 || tiles >= 192 || use_gemm256(M, N, K)) return 1;
-    int s = (int)(256 / tiles);
+    int s = (int)(256 / tiles);      // (512 workgroups - two per CU - measured the same to 3 %: S = 2048 4.86 vs 4.72 ms, S = 512 2.50 vs 2.52)
     if (s > 4) s = 4;
-    while (s > 1 && K / s < 512) --s;
+    while (s > 1 && (K / s < 512 || (gemm128s_ok(M, N, K) && K % (64 * s) != 0))) --s;
     return s < 1 ? 1 : s;
 }
 pgk_status engine_gemm_nt_slabs(const bf16* A, const void* W, float* slabs, int splits, int M, int N, int K, hipStream_t st) {
     PGK_REQUIRE(splits >= 2 && K % 8 == 0, "engine_gemm_nt_slabs: splits=%d K=%d", splits, K);
+    if (gemm128s_ok(M, N, K) && K % (64 * splits) == 0) return gemm128s_bf16_nt(A, (const bf16*)W, nullptr, slabs, 2, splits, M, N, K, st);
     return launch_mfma<bf16, 128, 128, B_NT, 2>(A, W, nullptr, nullptr, slabs, M, N, K, st, splits);
 }
 
@@ -418,6 +421,7 @@ pgk_status engine_gemm_nt(const bf16* A, const void* W, const bf16* wscale, bool
         return dispatch_mfma<bf16, B_NT_FP8, 0>(A, W, wscale, nullptr, C, M, N, K, st);
     }
     if (use_gemm256(M, N, K)) return gemm256_bf16_nt(A, (const bf16*)W, nullptr, C, accum_f32, M, N, K, st);
+    if (gemm128s_ok(M, N, K)) return gemm128s_bf16_nt(A, (const bf16*)W, nullptr, C, accum_f32 ? 1 : 0, 1, M, N, K, st);
     if (accum_f32) return dispatch_mfma<bf16, B_NT, 1>(A, W, nullptr, nullptr, C, M, N, K, st);
     return dispatch_mfma<bf16, B_NT, 0>(A, W, nullptr, nullptr, C, M, N, K, st);
 }
@@ -469,6 +473,7 @@ pgk_status pgk_gemm_nt(const void* a, const void* w, const void* bias, void* c, 
         return wsgemm_nt((const bf16*)a, k, w, nullptr, false, c, (const bf16*)bias, 0, 1, m, n, k, st);
     if (dt == PGK_BF16 && use_gemm256(m, n, k))
         return gemm256_bf16_nt((const bf16*)a, (const bf16*)w, (const bf16*)bias, c, false, m, n, k, st);
+    if (dt == PGK_BF16 && gemm128s_ok(m, n, k)) return gemm128s_bf16_nt((const bf16*)a, (const bf16*)w, (const bf16*)bias, c, 0, 1, m, n, k, st);
     if (dt == PGK_BF16) return dispatch_mfma<bf16, B_NT>((const bf16*)a, w, nullptr, (const bf16*)bias, (bf16*)c, m, n, k, st);
     return dispatch_mfma<f16, B_NT>((const f16*)a, w, nullptr, (const f16*)bias, (f16*)c, m, n, k, st);
 }

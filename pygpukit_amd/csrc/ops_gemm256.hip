@@ -342,6 +342,143 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A
     }
 }
 
+// ---- bf16, 128 x 128 tiles on the same staged LDS-DMA pipeline: the shapes too small for 192 tiles of 256 x 256 -------------
+// (Qwen3-0.6B at S = 2048: N = 1024 projections = 128 tiles, QKV 512 tiles with K = 1024.)  The register-staged 128-tile
+// kernel of ops_gemm.hip keeps ONE K step in flight (global -> registers -> LDS -> barrier): with one or two workgroups
+// per CU every step costs a memory round trip - 1.9 us per 64 k at M = 2048, N = 1024 (30 us for 8.6 GFLOP).  Here: 4 waves
+// (2 x 2, 64 x 64 each = 64 accumulator registers), stages of 32 k ([128 rows][64 B] per operand, 16 KiB per stage, the
+// swizzle of gemm256s), four stages of which three are in flight behind a counted vmcnt(8), ONE barrier per stage; 64 KiB
+// of LDS and < 128 registers, so two workgroups share a CU and one's MFMAs cover the other's barrier and fragment reads -
+// no stagger needed.  blockIdx.y = K split (EPI 2: fp32 slab z of [splits][M][N], summed by the consumer).
+// Epilogue through LDS: the fp32 tile (64 KiB = the four stages) is written with the lane quarters XOR-ed apart, then read
+// back as rows - 32 lanes x 16 B = one 512-byte row segment per instruction - for coalesced stores (EPI 1: float4
+// read-modify-write of the residual stream, all loads issued before the first store).
+constexpr int G1_THREADS = 256, G1_HALF = 128 * 64;
+template <int EPI>   // 0: bf16 C store (+bias); 1: fp32 C +=; 2: fp32 split-K slab
+__global__ __launch_bounds__(G1_THREADS, 2) void gemm128s_bf16_kernel(const bf16* A, const bf16* W, const bf16* bias, void* Cv,
+                                                                       int M, int N, int K, int ntm, int ntn, int kps) {
+    extern __shared__ __attribute__((aligned(16))) char g2_smem[];   // 4 stages x (A 8 KiB | W 8 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, q = lane >> 4, l15 = lane & 15;
+    int tm, tn;
+    g2_tile_of(blockIdx.x, ntm * ntn, ntm, ntn, tm, tn);
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int kbeg = (int)blockIdx.y * kps, kend = min(K, kbeg + kps);
+
+    const int drow = wid * 32 + (lane >> 2);                 // one DMA instruction = 16 rows x 64 B
+    const int dchunk = (lane & 3) ^ ((lane >> 4) & 2);
+    const bf16* a_src0 = A + (size_t)min(m0 + drow, M - 1) * K + kbeg + dchunk * 8;
+    const bf16* a_src1 = A + (size_t)min(m0 + drow + 16, M - 1) * K + kbeg + dchunk * 8;
+    const bf16* w_src0 = W + (size_t)min(n0 + drow, N - 1) * K + kbeg + dchunk * 8;
+    const bf16* w_src1 = W + (size_t)min(n0 + drow + 16, N - 1) * K + kbeg + dchunk * 8;
+    const uint32_t lds0 = g2_lds_addr(g2_smem);
+    const int nh = (kend - kbeg) / 32;
+    auto stage = [&](int h, int buf) {
+        const int k = min(h, nh - 1) * 32;                   // past the end: re-read the last stage (never consumed), the count stays constant
+        const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds0 + buf * 2 * G1_HALF + wid * 2048);
+        g2_dma16(a_src0 + k, a_dst);
+        g2_dma16(a_src1 + k, a_dst + 1024);
+        g2_dma16(w_src0 + k, a_dst + G1_HALF);
+        g2_dma16(w_src1 + k, a_dst + G1_HALF + 1024);
+    };
+
+    f32x4_g acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_g{0.f, 0.f, 0.f, 0.f};
+    const int f_off = l15 * 64 + ((q ^ ((l15 >> 2) & 2)) << 4);
+    const int a_base = wr * 64 * 64, w_base = G1_HALF + wc * 64 * 64;
+    uint4 fa[4], fb[4];
+
+    stage(0, 0);
+    stage(1, 1);
+    stage(2, 2);
+    // iteration s: own share of stage s landed (two younger stages may stay in flight) | barrier: everyone's share landed AND
+    // everyone finished reading stage s - 1, whose buffer the DMA of stage s + 3 - issued right behind the reads - refills
+#define G1S_STEP(S, BUF)                                                                                      \
+    {                                                                                                         \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                      \
+        __builtin_amdgcn_s_barrier();                                                                         \
+        const char* As = g2_smem + (BUF) * 2 * G1_HALF + a_base + f_off;                                      \
+        const char* Ws = g2_smem + (BUF) * 2 * G1_HALF + w_base + f_off;                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const uint4*>(As + i * 1024); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(Ws + j * 1024); \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        stage((S) + 3, ((BUF) + 3) & 3);                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_g, fa[i]),      \
+                                                                    __builtin_bit_cast(bf16x8_g, fb[j]), acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }
+    int s = 0;
+    for (; s + 4 <= nh; s += 4) {
+        G1S_STEP(s, 0) G1S_STEP(s + 1, 1) G1S_STEP(s + 2, 2) G1S_STEP(s + 3, 3)
+    }
+    if (s < nh) {   // (kend - kbeg) % 64 == 0: an even number of stages, so two remain at most
+        G1S_STEP(s, 0) G1S_STEP(s + 1, 1)
+    }
+#undef G1S_STEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // retire the phantom DMAs: the stages become the C tile
+    __builtin_amdgcn_s_barrier();
+
+    // fp32 tile [128][128]: row R's 64-byte group g at g ^ ((R >> 2) & 3) - (R >> 2) & 3 == q for the accumulator layout
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr * 64 + i * 16 + q * 4 + r, colb = (wc * 64 + j * 16 + l15) * 4;
+                *reinterpret_cast<float*>(g2_smem + row * 512 + (colb ^ (q << 6))) = acc[i][j][r];
+            }
+    __syncthreads();
+    if constexpr (EPI == 0) {
+        // 8 columns per lane: two float4 -> 16 bytes of bf16
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int item = it * G1_THREADS + tid, row = item >> 4, c = item & 15, sw = ((row >> 2) & 3) << 6;
+            const float4 v0 = *reinterpret_cast<const float4*>(g2_smem + row * 512 + ((c * 32) ^ sw));
+            const float4 v1 = *reinterpret_cast<const float4*>(g2_smem + row * 512 + ((c * 32 + 16) ^ sw));
+            const int grow = m0 + row, gcol = n0 + c * 8;
+            if (grow >= M || gcol >= N) continue;
+            float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if (bias) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += to_f(bias[gcol + e]);
+            }
+            Vec<bf16> o;
+            o.from_float(f);
+            o.store(reinterpret_cast<bf16*>(Cv) + (size_t)grow * N + gcol);
+        }
+    } else {
+        float* C = reinterpret_cast<float*>(Cv) + (EPI == 2 ? (size_t)blockIdx.y * M * N : 0);
+        float4 old[16];
+        if constexpr (EPI == 1) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int item = it * G1_THREADS + tid, row = item >> 5, c = item & 31;
+                const int grow = min(m0 + row, M - 1), gcol = min(n0 + c * 4, N - 4);
+                old[it] = *reinterpret_cast<const float4*>(C + (size_t)grow * N + gcol);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int item = it * G1_THREADS + tid, row = item >> 5, c = item & 31, sw = ((row >> 2) & 3) << 6;
+            float4 v = *reinterpret_cast<const float4*>(g2_smem + row * 512 + ((c * 16) ^ sw));
+            const int grow = m0 + row, gcol = n0 + c * 4;
+            if (grow >= M || gcol >= N) continue;
+            if constexpr (EPI == 1) { v.x += old[it].x; v.y += old[it].y; v.z += old[it].z; v.w += old[it].w; }
+            *reinterpret_cast<float4*>(C + (size_t)grow * N + gcol) = v;
+        }
+    }
+}
+
 // ---- fp8 x fp8 with 128-wide block scales on the same structure --------------------------------------------
 // K tile = 128 fp8 = one scale block: per tile the 256 row scales of A (fp32) and the two weight-block scales of
 // the tile's 256 columns (bf16) are DMA'd into a small LDS array next to the operand tiles - every global load
@@ -646,6 +783,29 @@ pgk_status gemm256_bf16_swiglu_nt(const bf16* A, const bf16* W, bf16* act, int M
     }
     const int ntm = ceil_div(M, G2_BM), ntn = I / 128;
     gemm256s_bf16_kernel<2><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, nullptr, act, M, I, K, ntm, ntn);
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
+}
+
+// 128 x 128 tiles; mode 0: bf16 C (+bias), 1: fp32 C +=, 2: fp32 slabs [splits][M][N] (K split into `splits` runs of whole 64-k steps)
+bool gemm128s_ok(int M, int N, int K) { return M > 128 && K % 64 == 0 && N % 8 == 0 && N >= 8; }
+pgk_status gemm128s_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, int mode, int splits, int M, int N, int K, hipStream_t st) {
+    PGK_REQUIRE(gemm128s_ok(M, N, K) && mode >= 0 && mode <= 2 && splits >= 1 && (splits == 1 || mode == 2), "gemm128s: M=%d N=%d K=%d mode=%d splits=%d", M, N, K, mode, splits);
+    constexpr size_t LDS = 8 * (size_t)G1_HALF;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128s_bf16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128s_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128s_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        attr_done = true;
+    }
+    const int ntm = ceil_div(M, 128), ntn = ceil_div(N, 128);
+    const int kps = ceil_div(ceil_div(K, splits), 64) * 64;
+    const dim3 grid(ntm * ntn, ceil_div(K, kps));
+    PGK_REQUIRE((int)grid.y == splits, "gemm128s: K=%d does not split into %d runs of whole 64-k steps", K, splits);
+    if (mode == 0) gemm128s_bf16_kernel<0><<<grid, G1_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn, kps);
+    else if (mode == 1) gemm128s_bf16_kernel<1><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps);
+    else gemm128s_bf16_kernel<2><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps);
     PGK_CHECK_HIP(hipGetLastError());
     return PGK_OK;
 }

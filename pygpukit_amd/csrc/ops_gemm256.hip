@@ -120,6 +120,48 @@ __device__ __forceinline__ void g2_swiglu_epilogue(char* smem, const f32x4_g (&a
     }
 }
 
+// ---- fp32 "+=" epilogue (EPI 1) through LDS: the residual stream is read and written as whole 512-byte row segments ---------
+// The direct form - every lane adds its 128 accumulators to 128 separate words, 16 lanes per 64 contiguous bytes - cost
+// ~30-40 us per launch at the Llama shapes (o_proj 161 us against 121 for the bf16-store kernel of the same product), all of
+// it exposed: a one-wave grid has no second tile to hide an epilogue behind.  Here, per 64-column quarter of the tile: the
+// residual words are requested first (8 float4 per lane), the owning wave column puts its accumulators into LDS ([256][64]
+// fp32 over the operand stages, lane quarters XOR-ed apart), and every lane adds and stores 8 float4 (256-byte row segments).
+__device__ __forceinline__ void g2_accum_epilogue(char* smem, const f32x4_g (&acc)[8][4], int tid, int m0, int n0, int M, int N, float* C) {
+    const int lane = tid & 63, wid = tid >> 6, wr = wid >> 2, wc = wid & 3, q = lane >> 4, l15 = lane & 15;
+    // one pass per 64-column quarter (= one wave column): 8 float4 per lane in flight (16 - halves - spilled in these kernels)
+#pragma unroll 1
+    for (int h = 0; h < 4; ++h) {
+        float4 old[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int item = it * G2_THREADS + tid, row = item >> 4, c = item & 15;
+            old[it] = *reinterpret_cast<const float4*>(C + (size_t)min(m0 + row, M - 1) * N + min(n0 + h * 64 + c * 4, N - 4));
+        }
+        __syncthreads();                             // operand stages (h = 0) / the previous quarter's tile are no longer read
+        if (wc == h) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = wr * 128 + i * 16 + q * 4 + r, colb = (j * 16 + l15) * 4;
+                        *reinterpret_cast<float*>(smem + row * 256 + (colb ^ (q << 6))) = acc[i][j][r];      // (row >> 2) & 3 == q
+                    }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int item = it * G2_THREADS + tid, row = item >> 4, c = item & 15, sw = ((row >> 2) & 3) << 6;
+            float4 v = *reinterpret_cast<const float4*>(smem + row * 256 + ((c * 16) ^ sw));
+            const int grow = m0 + row, gcol = n0 + h * 64 + c * 4;
+            if (grow >= M || gcol >= N) continue;
+            v.x += old[it].x; v.y += old[it].y; v.z += old[it].z; v.w += old[it].w;
+            *reinterpret_cast<float4*>(C + (size_t)grow * N + gcol) = v;
+        }
+    }
+}
+
 template <int EPI>   // 0: bf16 C store (+bias); 1: fp32 C +=
 __global__ __launch_bounds__(G2_THREADS) void gemm256_bf16_kernel(const bf16* A, const bf16* W, const bf16* bias, void* Cv,
                                                                    int M, int N, int K, int ntm, int ntn) {
@@ -323,6 +365,12 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A
     if constexpr (EPI == 2) {
         g2_swiglu_epilogue<false>(g2_smem, acc, tid, m0, tn, M, N, Cv, nullptr);
         return;
+    }
+    if constexpr (EPI == 1) {
+        if ((N & 3) == 0) {       // whole float4s per row (every engine shape); otherwise the word-wise form below
+            g2_accum_epilogue(g2_smem, acc, tid, m0, n0, M, N, reinterpret_cast<float*>(Cv));
+            return;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -689,6 +737,10 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
 
     if constexpr (EPI == 2) {
         g2_swiglu_epilogue<true>(g2_smem, acc, tid, m0, tn, M, N, Cv, Cs);
+        return;
+    }
+    if constexpr (EPI == 1) {     // N % 256 == 0 here
+        g2_accum_epilogue(g2_smem, acc, tid, m0, n0, M, N, reinterpret_cast<float*>(Cv));
         return;
     }
 #pragma unroll

@@ -5,9 +5,11 @@ FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts half the
 (128-byte requests tallied as 64): reads are doubled, writes taken as they are (guide, section HBM)."""
 import collections, csv, glob, json, sys
 
-CLASS = [("attn_oproj_", "attn"), ("finalize_kernel", "argmax"),
-         ("fused_gemv_kernel<pgk::bf16, float, 1, 4, 0, 0,", "norm_qkv"), ("fused_gemv_kernel<pgk::bf16, float, 1, 2, 3, 2,", "gateup"),
-         ("fused_gemv_kernel<pgk::bf16, float, 1, 1, 1, 1,", "down"), ("fused_gemv_kernel<pgk::bf16, float, 1, 4, 0, 3,", "lmhead")]
+import re
+# fused_gemv_kernel<weights, activations, M, rows per wave, prologue, epilogue, chunks>: classes by (prologue, epilogue)
+CLASS = [(re.compile(r"attn_oproj_"), "attn"), (re.compile(r"finalize_kernel"), "argmax"),
+         (re.compile(r"fused_gemv_kernel<pgk::bf16, float, 1, \d+, 0, 0,"), "norm_qkv"), (re.compile(r"fused_gemv_kernel<pgk::bf16, float, 1, \d+, 3, 2,"), "gateup"),
+         (re.compile(r"fused_gemv_kernel<pgk::bf16, float, 1, \d+, 1, 1,"), "down"), (re.compile(r"fused_gemv_kernel<pgk::bf16, float, 1, \d+, 0, 3,"), "lmhead")]
 
 
 def collect(d, counter):
@@ -30,7 +32,7 @@ for name in sorted(set(fetch) | set(write)):
            "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wb, "hbm_bytes_per_launch": rd + wb}
     out["by_name"][name] = rec
     for pat, cls in CLASS:
-        if pat in name and len(fr) >= 20 or (pat in name and cls in ("lmhead", "argmax") and len(fr) >= 8):
+        if pat.search(name) and (len(fr) >= 20 or (cls in ("lmhead", "argmax") and len(fr) >= 8)):
             out["kernels"][cls] = dict(rec, kernel=name)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))

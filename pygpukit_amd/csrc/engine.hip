@@ -42,6 +42,9 @@ pgk_status engine_gemm_nt_slabs(const bf16* A, const void* W, float* slabs, int 
 pgk_status gemm_fp8_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, void* c, bool accum_f32, int M,
                        int N, int K, hipStream_t st);
 pgk_status quantize_fp8_rows_bf16(const bf16* x, uint8_t* out, float* scale, int M, int K, hipStream_t st);
+bool sdpa_flash_enabled();                                     // ops_attention.hip: PYGPUKIT_FLASH_ATTENTION
+pgk_status flash_prefill_q8(const void* q, const void* k, const void* v, uint8_t* q8, float* q8s, int hq, int hkv, int q_len, int kv_len,
+                            float scale, long long qh, long long qs, long long kh, long long ks, hipStream_t st);   // ops_flash.hip
 bool engine_gemm_swiglu_ok(int M, int I, int K, bool fp8);     // ops_gemm.hip: gate / up projection with the SwiGLU epilogue
 pgk_status engine_gemm_swiglu_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, bf16* act, int M, int I, int K, hipStream_t st);
 bool gemm_fp8_swiglu_ok(int M, int I, int K);                  // ops_fp8_gemm.hip: ... and the e4m3 quantisation of the result
@@ -2441,8 +2444,14 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
                     slabs, s_qkv > 1 ? s_qkv : 0);
             PGK_LAUNCH_CHECK();
         }
-        if (pgk_status r = pgk_sdpa_causal(qkv, kc, vc, attn, c.num_heads, c.num_kv_heads, n, kv_len, D, 0.f, D, NQKV,
-                                           (int64_t)c.max_seq_len * D, D, D, QD, PGK_BF16, st))
+        // fp8 x fp8: a head's 128 output dims are one scale block of the o_proj operand, so the flash kernel quantises them itself
+        const bool attn_q8 = fuse_q && D == 128 && n > 128 && sdpa_flash_enabled();
+        if (attn_q8) {
+            if (pgk_status r = flash_prefill_q8(qkv, kc, vc, q8, q8s, c.num_heads, c.num_kv_heads, n, kv_len, 1.0f / sqrtf((float)D), D, NQKV,
+                                                (long long)c.max_seq_len * D, D, st))
+                return r;
+        } else if (pgk_status r = pgk_sdpa_causal(qkv, kc, vc, attn, c.num_heads, c.num_kv_heads, n, kv_len, D, 0.f, D, NQKV,
+                                                  (int64_t)c.max_seq_len * D, D, D, QD, PGK_BF16, st))
             return r;
         // N = hidden projections of the packed path: fp32 split-K slabs summed by the next norm (or h32 += with one split)
         auto pk_accum = [&](const bf16* x_in, const bf16* wp, int K_, int splits) -> pgk_status {
@@ -2462,7 +2471,7 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
             continue;
         }
         if (pk) { if (pgk_status r = pk_accum(attn, e->packed[l].o, QD, pk_so)) return r; }
-        else if (pgk_status r = proj_accum(attn, L.w_o, L.s_o, H, QD, s_o)) return r;
+        else if (pgk_status r = proj_accum(attn_q8 ? nullptr : attn, L.w_o, L.s_o, H, QD, s_o)) return r;
         if (pgk_status r = norm((const bf16*)L.mlp_norm, fuse_q)) return r;
         if (pk) {
             // SwiGLU inside the gate_up projection: the gate tile and its up tile live in the same wave

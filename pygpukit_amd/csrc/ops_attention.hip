@@ -425,6 +425,8 @@ static bool flash_decoding_off() {
     return e && atoi(e) == 0 && strcmp(e, "auto") != 0;
 }
 
+bool sdpa_flash_enabled() { return !flash_attention_off(); }   // for the engine's direct use of ops_flash.hip
+
 template <class T>
 static pgk_status sdpa_dispatch(const void* q, const void* k, const void* v, void* out, int hq, int hkv, int q_len,
                                 int kv_len, int d, float scale, const AttnStrides& sd, hipStream_t st) {

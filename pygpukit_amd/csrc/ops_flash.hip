@@ -61,6 +61,12 @@ struct FlashSplit {
     int nsplit;
     float* ml;      // [nsplit][Hq][q_len][2]  (m in the exp2 domain, l)
     void* o;        // [nsplit][q_len][Hq][D] of T
+    // fp8 x fp8 prefill (D = 128, bf16): instead of out, e4m3 codes [q_len][Hq * D] and one scale per (row, head) [q_len][Hq]
+    // - a head's 128 output dims ARE one 128-wide scale block of the o_proj's A operand (quantize_fp8_rows' contract:
+    // scale = absmax / 448 of the bf16-rounded values, 1 for an all-zero block), written by whichever kernel holds the final
+    // row: this one (nsplit == 1) or flash_merge_kernel
+    uint8_t* q8;
+    float* q8s;
 };
 
 template <class T, int D>
@@ -302,6 +308,32 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     const int qrow = qw0 + ql;
+    if constexpr (std::is_same<T, bf16>::value && D == 128) {
+        if (sp.q8 != nullptr && sp.nsplit == 1) {       // workgroup-uniform
+            // the lane's 64 dims (the partner lane ^ 32 holds the other 64), rounded to bf16 as the plain store would
+            float amax = 0.f;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    o[i][e] = __uint_as_float(pack_bf16x2(o[i][e] * inv, 0.f) << 16);
+                    amax = fmaxf(amax, fabsf(o[i][e]));
+                }
+            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+            const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+            if (qrow < q_len) {
+                uint8_t* qrow8 = sp.q8 + ((size_t)qrow * hq + head) * D;
+#pragma unroll
+                for (int i = 0; i < DT; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<uint32_t*>(qrow8 + i * 32 + 8 * g + 4 * h) =
+                            pack_fp8x4(o[i][4 * g] / sc, o[i][4 * g + 1] / sc, o[i][4 * g + 2] / sc, o[i][4 * g + 3] / sc);
+                if (h == 0) sp.q8s[(size_t)qrow * hq + head] = sc;
+            }
+            return;
+        }
+    }
     if (qrow < q_len) {
         T* orow = sp.nsplit > 1 ? reinterpret_cast<T*>(sp.o) + (((size_t)split * q_len + qrow) * hq + head) * D
                                 : out + (size_t)head * sd.oh + (size_t)qrow * sd.os;
@@ -324,11 +356,12 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
 
 // out[q][head][:] = sum_s w_s o_s / sum_s w_s,  w_s = l_s 2^(m_s - max m): one thread per 8 output elements
 template <class T, int D>
-__global__ __launch_bounds__(256) void flash_merge_kernel(const float* ml, const T* po, T* out, int hq, int q_len, int nsplit, long long oh, long long os) {
+__global__ __launch_bounds__(256) void flash_merge_kernel(const float* ml, const T* po, T* out, int hq, int q_len, int nsplit, long long oh, long long os,
+                                                          uint8_t* q8 = nullptr, float* q8s = nullptr) {
     constexpr int CPR = D / 8;
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t nrow = (size_t)q_len * hq;
-    if (gid >= nrow * CPR) return;
+    if (gid >= nrow * CPR) return;          // nrow * CPR is a multiple of 16: the 16 lanes of a (row, head) stay together
     const size_t rowi = gid / CPR;
     const int c = (int)(gid % CPR), qrow = (int)(rowi / hq), head = (int)(rowi % hq);
     float mstar = -INFINITY;
@@ -352,6 +385,22 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(const float* ml, const
     for (int j = 0; j < 8; ++j) acc[j] *= inv;
     Vec<T> v;
     v.from_float(acc);
+    if constexpr (std::is_same<T, bf16>::value && D == 128) {
+        if (q8 != nullptr) {                // see FlashSplit::q8: 16 lanes x 8 dims = one (row, head) = one scale block
+            v.to_float(acc);
+            float amax = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(acc[j]));
+            amax = group16_max(amax);
+            const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+            uint2 o8;
+            o8.x = pack_fp8x4(acc[0] / sc, acc[1] / sc, acc[2] / sc, acc[3] / sc);
+            o8.y = pack_fp8x4(acc[4] / sc, acc[5] / sc, acc[6] / sc, acc[7] / sc);
+            *reinterpret_cast<uint2*>(q8 + rowi * D + c * 8) = o8;
+            if (c == 0) q8s[rowi] = sc;
+            return;
+        }
+    }
     v.store(out + (size_t)head * oh + (size_t)qrow * os + c * 8);
 }
 
@@ -387,7 +436,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const T* v, T* vt, int
 
 template <class T, int D>
 static pgk_status flash_launch(const T* q, const T* k, const T* v, T* out, int hq, int hkv, int q_len, int kv_len, float scale,
-                               const FlashStrides& sd, hipStream_t st) {
+                               const FlashStrides& sd, hipStream_t st, uint8_t* q8 = nullptr, float* q8s = nullptr) {
     const int kv_pad = ceil_div(kv_len, 64) * 64;
     const int nqt = ceil_div(q_len, FL_BQ);
     // KV runs per query tile: enough workgroups for two per CU (the kernel's occupancy), never more runs than the
@@ -407,7 +456,7 @@ static pgk_status flash_launch(const T* q, const T* k, const T* v, T* out, int h
     if (pgk_status r = pgk_malloc(&ws, vt_bytes + po_bytes + ml_bytes + 512)) return r;
     char* base = (char*)ws;
     T* vt = (T*)base;
-    FlashSplit sp{nsplit, nullptr, nullptr};
+    FlashSplit sp{nsplit, nullptr, nullptr, q8, q8s};
     if (nsplit > 1) {
         sp.o = base + ((vt_bytes + 255) & ~(size_t)255);
         sp.ml = (float*)((char*)sp.o + ((po_bytes + 255) & ~(size_t)255));
@@ -425,7 +474,7 @@ static pgk_status flash_launch(const T* q, const T* k, const T* v, T* out, int h
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && nsplit > 1) {
         const size_t work = (size_t)q_len * hq * (D / 8);
-        flash_merge_kernel<T, D><<<(unsigned)((work + 255) / 256), 256, 0, st>>>(sp.ml, (const T*)sp.o, out, hq, q_len, nsplit, sd.oh, sd.os);
+        flash_merge_kernel<T, D><<<(unsigned)((work + 255) / 256), 256, 0, st>>>(sp.ml, (const T*)sp.o, out, hq, q_len, nsplit, sd.oh, sd.os, q8, q8s);
         e = hipGetLastError();
     }
     pgk_free(ws);   // stream-ordered reuse: later work on this stream runs after the kernels above
@@ -444,6 +493,15 @@ pgk_status flash_prefill(const void* q, const void* k, const void* v, void* out,
     }
     if (d == 128) return flash_launch<f16, 128>((const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, hq, hkv, q_len, kv_len, scale, sd, st);
     return flash_launch<f16, 64>((const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, hq, hkv, q_len, kv_len, scale, sd, st);
+}
+
+// engine entry (fp8 x fp8 prefill, bf16, head_dim 128, q_len > 128): causal attention whose result leaves as the o_proj's fp8
+// operand - codes [q_len][hq * 128] + scales [q_len][hq] - instead of bf16 rows (FlashSplit::q8)
+pgk_status flash_prefill_q8(const void* q, const void* k, const void* v, uint8_t* q8, float* q8s, int hq, int hkv, int q_len, int kv_len,
+                            float scale, long long qh, long long qs, long long kh, long long ks, hipStream_t st) {
+    PGK_REQUIRE(q8 && q8s && q_len > 128, "flash_prefill_q8: needs output buffers and q_len > 128 (got %d)", q_len);
+    const FlashStrides sd{qh, qs, kh, ks, 0, 0};
+    return flash_launch<bf16, 128>((const bf16*)q, (const bf16*)k, (const bf16*)v, nullptr, hq, hkv, q_len, kv_len, scale, sd, st, q8, q8s);
 }
 
 }  // namespace pgk

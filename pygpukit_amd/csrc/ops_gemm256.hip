@@ -281,24 +281,30 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_bf16_kernel(const bf16* A,
 // lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32), not in runs of 16 lanes: the first version's swizzle
 // (r >> 2) & 3 was conflict-free for runs of 16 and 2-way conflicted for the real groups (SQ_LDS_BANK_CONFLICT = half of
 // SQ_LDS_IDX_ACTIVE, profiles/r03_gemm_pmc.txt); (r >> 2) & 2 is conflict-free for them (exhaustive check).
-template <int EPI>   // 0: bf16 C store (+bias); 1: fp32 C +=; 2: SwiGLU (W = fused gate / up rows, N = I act columns, C = bf16 act [M][I])
+// TN = n-fragments per wave column: 4 = 256-column tiles; 3 = 192-column tiles (EPI 0 only), for shapes whose 256-tiles leave a
+// half-empty last round: Llama's QKV (4096 x 6144) is 384 tiles = 1.5 rounds of the 256 CUs, 512 tiles of 256 x 192 are two
+// full rounds of three quarters the work.  The W stage then has 192 rows = 12 DMA instructions: waves 0-3 move two (rows 0-127),
+// waves 4-7 one (rows 128-191), so the "two younger stages in flight" count is vmcnt(8) for the former, vmcnt(6) for the latter.
+template <int EPI, int TN = 4>   // EPI 0: bf16 C store (+bias); 1: fp32 C +=; 2: SwiGLU (W = fused gate / up rows, N = I act columns, C = bf16 act [M][I])
 __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A, const bf16* W, const bf16* bias, void* Cv,
                                                                     int M, int N, int K, int ntm, int ntn) {
+    static_assert(TN == 4 || (TN == 3 && EPI == 0), "192-column tiles: plain bf16 store only");
     extern __shared__ __attribute__((aligned(16))) char g2_smem[];   // 4 stages x (A 16 KiB | W 16 KiB)
-    constexpr int HALF = 256 * 64;
+    constexpr int HALF = 256 * 64, BN = TN * 64, WN = TN * 16;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 2, wc = wid & 3, q = lane >> 4, l15 = lane & 15;
     const int late = __builtin_amdgcn_readfirstlane(wr);     // wave-uniform by construction: scalar branches around barriers
     int tm, tn;
     g2_tile_of(blockIdx.x, ntm * ntn, ntm, ntn, tm, tn);
-    const int m0 = tm * G2_BM, n0 = tn * G2_BN;
+    const int m0 = tm * G2_BM, n0 = tn * BN;
 
     const int drow = wid * 32 + (lane >> 2);                 // one DMA instruction = 16 rows x 64 B
     const int dchunk = (lane & 3) ^ ((lane >> 4) & 2);      // = (lane & 3) ^ g2s_sw(row & 15), row & 15 = lane >> 2
     const bf16* a_src0 = A + (size_t)min(m0 + drow, M - 1) * K + dchunk * 8;
     const bf16* a_src1 = A + (size_t)min(m0 + drow + 16, M - 1) * K + dchunk * 8;
     // B-tile row r of an EPI-2 workgroup: gate row 128 tn + r for r < 128, up row N + 128 tn + (r - 128) after that (N = I)
-    const int wrow = (EPI == 2) ? (drow < 128 ? tn * 128 + drow : N + tn * 128 + drow - 128) : n0 + drow;
+    const int wtile_row = (TN == 4 || !late) ? drow : 128 + (wid - 4) * 16 + (lane >> 2);
+    const int wrow = (EPI == 2) ? (drow < 128 ? tn * 128 + drow : N + tn * 128 + drow - 128) : n0 + wtile_row;
     const int wlast = (EPI == 2) ? 2 * N - 1 : N - 1;
     const bf16* w_src0 = W + (size_t)min(wrow, wlast) * K + dchunk * 8;
     const bf16* w_src1 = W + (size_t)min(wrow + 16, wlast) * K + dchunk * 8;
@@ -309,23 +315,36 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A
         const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds0 + buf * 2 * HALF + wid * 2048);
         g2_dma16(a_src0 + k, a_dst);
         g2_dma16(a_src1 + k, a_dst + 1024);
-        g2_dma16(w_src0 + k, a_dst + HALF);
-        g2_dma16(w_src1 + k, a_dst + HALF + 1024);
+        if constexpr (TN == 4) {
+            g2_dma16(w_src0 + k, a_dst + HALF);
+            g2_dma16(w_src1 + k, a_dst + HALF + 1024);
+        } else if (!late) {
+            g2_dma16(w_src0 + k, a_dst + HALF);
+            g2_dma16(w_src1 + k, a_dst + HALF + 1024);
+        } else {
+            g2_dma16(w_src0 + k, __builtin_amdgcn_readfirstlane(lds0 + buf * 2 * HALF + HALF + 128 * 64 + (wid - 4) * 1024));
+        }
+    };
+    // "this wave's share of the oldest of three stages in flight has landed"
+    auto wait_two_younger = [&]() {
+        if constexpr (TN == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (late) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     };
 
-    f32x4_g acc[8][4];
+    f32x4_g acc[8][TN];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_g{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_g{0.f, 0.f, 0.f, 0.f};
     const int f_off = l15 * 64 + ((q ^ ((l15 >> 2) & 2)) << 4);
-    const int a_base = wr * 128 * 64, w_base = HALF + wc * 64 * 64;
-    uint4 fa[8], fb[4];
+    const int a_base = wr * 128 * 64, w_base = HALF + wc * WN * 64;
+    uint4 fa[8], fb[TN];
 
     stage(0, 0);
     stage(1, 1);
     stage(2, 2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    wait_two_younger();
     __builtin_amdgcn_s_barrier();
     if (late) __builtin_amdgcn_s_barrier();                  // waves 4-7 start one phase behind
 #define G2S_STEP(S, BUF)                                                                                     \
@@ -333,22 +352,22 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A
         const char* As = g2_smem + (BUF) * 2 * HALF + a_base + f_off;                                        \
         const char* Ws = g2_smem + (BUF) * 2 * HALF + w_base + f_off;                                        \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const uint4*>(As + i * 1024); \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(Ws + j * 1024); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(Ws + j * 1024); \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         stage((S) + 3, ((BUF) + 3) & 3);                                                                     \
-        if (late) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                \
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              \
+        if (late) wait_two_younger();                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
         __builtin_amdgcn_s_barrier();                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         /* phase B */                                                                                        \
         __builtin_amdgcn_s_setprio(1);                                                                       \
         _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                        \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_g, fa[i]),     \
                                                                     __builtin_bit_cast(bf16x8_g, fb[j]), acc[i][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        if (!late) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                          \
+        if (!late) wait_two_younger();                                                                       \
         __builtin_amdgcn_s_barrier();                                                                        \
     }
     int s = 0;
@@ -362,19 +381,19 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A
     if (!late) __builtin_amdgcn_s_barrier();                 // match the extra barrier of waves 4-7
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // retire the phantom DMAs before the LDS is given back
 
-    if constexpr (EPI == 2) {
+    if constexpr (EPI == 2 && TN == 4) {
         g2_swiglu_epilogue<false>(g2_smem, acc, tid, m0, tn, M, N, Cv, nullptr);
         return;
     }
-    if constexpr (EPI == 1) {
+    if constexpr (EPI == 1 && TN == 4) {
         if ((N & 3) == 0) {       // whole float4s per row (every engine shape); otherwise the word-wise form below
             g2_accum_epilogue(g2_smem, acc, tid, m0, n0, M, N, reinterpret_cast<float*>(Cv));
             return;
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wc * 64 + j * 16 + l15;
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wc * WN + j * 16 + l15;
         if (col >= N) continue;
         float b = 0.f;
         if constexpr (EPI == 0) b = bias ? to_f(bias[col]) : 0.f;
@@ -813,7 +832,18 @@ pgk_status gemm256_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void*
             PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
             attr_s = true;
         }
-        if (accum_f32) gemm256s_bf16_kernel<1><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn);
+        // 192-column tiles when they fill the rounds of the chip better (cost = rounds x work per tile)
+        const int ntn3 = N / 192;
+        const bool narrow = !accum_f32 && N % 192 == 0 &&
+                            0.75 * ceil_div(ntm * ntn3, 256) < (double)ceil_div(ntm * ntn, 256) - 0.01;
+        if (narrow) {
+            static bool attr_n = false;
+            if (!attr_n) {
+                PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_bf16_kernel<0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+                attr_n = true;
+            }
+            gemm256s_bf16_kernel<0, 3><<<ntm * ntn3, G2_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn3);
+        } else if (accum_f32) gemm256s_bf16_kernel<1><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn);
         else gemm256s_bf16_kernel<0><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn);
         PGK_CHECK_HIP(hipGetLastError());
         return PGK_OK;

@@ -446,10 +446,11 @@ def test_w8a16_gemm_kn(m):
 
 
 # ----------------------------------------------------------------------------- 256 x 256 LDS-DMA GEMM
-@pytest.mark.parametrize("shape", [(256, 256, 64), (512, 768, 256), (300, 520, 192), (1000, 260, 1024)])
+@pytest.mark.parametrize("shape", [(256, 256, 64), (512, 768, 256), (300, 520, 192), (1000, 260, 1024), (300, 576, 192), (700, 192, 320)])
 def test_gemm256_bf16_matches_oracle_and_128_tile_kernel(shape, monkeypatch):
     """The large-tile kernel (LDS-DMA staging, source-side swizzle) against the oracle, on shapes with ragged M / N
-    edges and several K tiles; the 128-tile kernel on the same inputs must agree to bf16 rounding of the same sums."""
+    edges and several K tiles; the 128-tile kernel on the same inputs must agree to bf16 rounding of the same sums.
+    N = 768 / 576 / 192 take the 192-column tile variant (a W stage of 12 DMA instructions split 2 + 1 over the wave halves)."""
     M, N, K = shape
     rng = np.random.default_rng(31)
     a = rng.standard_normal((M, K)).astype(np.float32)
@@ -483,10 +484,11 @@ def test_w8a16_gemm_large_goes_through_dequant_and_gemm256(monkeypatch):
     assert rel_err(c256, ref) < 1e-2 and rel_err(c128, ref) < 1e-2 and rel_err(c256, c128) < 3e-3
 
 
-def test_gemm256_exact_integers(monkeypatch):
-    """Small integers are exact in bf16 and fp32: the two kernels and the oracle must agree bit for bit."""
+@pytest.mark.parametrize("N", [512, 384])
+def test_gemm256_exact_integers(N, monkeypatch):
+    """Small integers are exact in bf16 and fp32: the two kernels and the oracle must agree bit for bit (N = 384: 192-column tiles)."""
     rng = np.random.default_rng(32)
-    M, N, K = 512, 512, 128
+    M, K = 512, 128
     a = rng.integers(-3, 4, (M, K)).astype(np.float32)
     w = rng.integers(-3, 4, (N, K)).astype(np.float32)
     monkeypatch.setenv("PGK_GEMM256", "1")

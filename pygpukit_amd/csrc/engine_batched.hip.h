@@ -238,13 +238,16 @@ __global__ __launch_bounds__(256) void batched_mfma_kernel(unsigned long long* t
 // and the epilogue ignores those columns (the MFMA computes them on whatever the registers hold - columns are
 // independent).
 template <class WT, int PRO, int EPI, int S, int RPG>
-__global__ __launch_bounds__(256) void batched_reg_kernel(unsigned long long* tl, FusedArgs a, int M, int nblk_logits) {
+__global__ __launch_bounds__(256) void batched_reg_kernel(unsigned long long* tl, const void* w_, const bf16* wp_, const float* x_, const bf16* gamma_,
+                                                          int N_, int K_, int M, int nblk_logits, FusedArgs a) {
+    // the first 14 dwords of the arguments - everything the load-issue phase needs - arrive preloaded in SGPRs (see fused_gemv_kernel,
+    // engine.hip): w_ / wp_ = FusedArgs::w / wp, x_ = the fp32 input rows (h for the norm prologue, xin otherwise), gamma_, N_, K_
     const TLStamp tls(tl);
     constexpr bool FP8 = std::is_same<WT, fp8e4m3>::value;
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
     __shared__ float s_ss[4][16];
     __shared__ float red[NT * 4 * 256];                    // [NT][4 waves][16 m][16 n]
-    const int K = a.K, N = a.N;
+    const int K = K_, N = N_;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, q = lane >> 4, l15 = lane & 15;
     const int ngroups = (N + RPG - 1) / RPG;
     const int kw0 = wid * S * 32;
@@ -257,11 +260,11 @@ __global__ __launch_bounds__(256) void batched_reg_kernel(unsigned long long* tl
             // fragment-major copy (ops_pkgemm.hip): block (n-tile, k-step) is this very fragment, 1 KiB in lane order - one
             // coalesced load per k-step instead of 64 separate 16-byte pieces of a row-major matrix (3.5x the texture
             // addresser's time per instruction, tools/micro/ta_probe.hip).  Used where a workgroup streams many groups (lm_head).
-            if (a.wp != nullptr && n0 + 16 <= N) {
+            if (wp_ != nullptr && n0 + 16 <= N) {
                 const int ksn = K >> 5;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const bf16* run = a.wp + (((size_t)((t == 0 ? n0 : N + n0) >> 4) * ksn + (kw0 >> 5)) * 64 + lane) * 8;
+                    const bf16* run = wp_ + (((size_t)((t == 0 ? n0 : N + n0) >> 4) * ksn + (kw0 >> 5)) * 64 + lane) * 8;
 #pragma unroll
                     for (int s = 0; s < S; ++s) wv[t][s] = load_nt16(run + (size_t)s * 512);
                 }
@@ -276,11 +279,11 @@ __global__ __launch_bounds__(256) void batched_reg_kernel(unsigned long long* tl
                 for (int s = 0; s < S; ++s) {
                     const int k = kw0 + s * 32 + 8 * q;
                     if constexpr (FP8) {
-                        const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(a.w) + row * K + k);
+                        const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(w_) + row * K + k);
                         wv[t][s] = make_uint4(v.x, v.y, 0, 0);
                         wsc[t][s] = to_f(a.wscale[(row >> 7) * (size_t)(K >> 7) + (k >> 7)]);
                     } else {
-                        wv[t][s] = load_nt16(reinterpret_cast<const bf16*>(a.w) + row * K + k);
+                        wv[t][s] = load_nt16(reinterpret_cast<const bf16*>(w_) + row * K + k);
                     }
                 }
             }
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256) void batched_reg_kernel(unsigned long long* tl
     // Issue order = arrival order: the activation rows (L2) are requested BEFORE the weight stream (HBM), so the RMSNorm
     // statistic, its barrier and the bf16 conversion run while the weights are still in flight (the other way round the
     // prologue started when the last weight byte had landed - the batch-1 kernels' lesson).
-    const float* src = ((PRO == PRO_NORM) ? a.h : a.xin) + (size_t)min(l15, M - 1) * K + kw0 + 8 * q;
+    const float* src = x_ + (size_t)min(l15, M - 1) * K + kw0 + 8 * q;
     uint4 af[S];
     constexpr bool HOLD_FIRST = PRO == PRO_NORM && S <= 8;      // raw rows held in registers across the reduction
     if constexpr (!HOLD_FIRST) load_w(blockIdx.x * RPG);        // (deep K: the rows are re-read after the barrier anyway)
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(256) void batched_reg_kernel(unsigned long long* tl
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             Vec<bf16> gr;
-            gr.load(a.gamma + kw0 + s * 32 + 8 * q);
+            gr.load(gamma_ + kw0 + s * 32 + 8 * q);
             float g[8];
             gr.to_float(g);
             if constexpr (HOLD) {
@@ -659,10 +662,11 @@ static pgk_status launch_batched_reg(const FusedArgs& a, int M, hipStream_t st, 
     // enough workgroups to pull HBM bandwidth: fewer weight rows per workgroup when N / 16 would leave CUs idle
     int rpg = (EPI == EPI_LOGITS || ceil_div(a.N, 16) >= 192) ? 16 : (ceil_div(a.N, 8) >= 192 ? 8 : 4);
     const int grid = (EPI == EPI_LOGITS) ? nblk_logits : ceil_div(a.N, rpg);
+    const float* x = (PRO == PRO_NORM) ? a.h : a.xin;
     hipError_t he;
-    if (rpg == 16) he = launch_k(batched_reg_kernel<WT, PRO, EPI, S, 16>, dim3(grid), dim3(256), 0, st, a, M, nblk_logits);
-    else if (rpg == 8) he = launch_k(batched_reg_kernel<WT, PRO, EPI, S, 8>, dim3(grid), dim3(256), 0, st, a, M, nblk_logits);
-    else he = launch_k(batched_reg_kernel<WT, PRO, EPI, S, 4>, dim3(grid), dim3(256), 0, st, a, M, nblk_logits);
+    if (rpg == 16) he = launch_k(batched_reg_kernel<WT, PRO, EPI, S, 16>, dim3(grid), dim3(256), 0, st, a.w, a.wp, x, a.gamma, a.N, a.K, M, nblk_logits, a);
+    else if (rpg == 8) he = launch_k(batched_reg_kernel<WT, PRO, EPI, S, 8>, dim3(grid), dim3(256), 0, st, a.w, a.wp, x, a.gamma, a.N, a.K, M, nblk_logits, a);
+    else he = launch_k(batched_reg_kernel<WT, PRO, EPI, S, 4>, dim3(grid), dim3(256), 0, st, a.w, a.wp, x, a.gamma, a.N, a.K, M, nblk_logits, a);
     PGK_CHECK_HIP(he);
     return PGK_OK;
 }

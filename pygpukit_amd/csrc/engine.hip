@@ -28,6 +28,7 @@
 
 #include "attn_core.hip.h"
 #include "engine_common.hip.h"
+#include "gemm_epilogues.hip.h"
 #include "pkgemm.hip.h"
 
 namespace pgk {
@@ -45,6 +46,8 @@ pgk_status quantize_fp8_rows_bf16(const bf16* x, uint8_t* out, float* scale, int
 bool sdpa_flash_enabled();                                     // ops_attention.hip: PYGPUKIT_FLASH_ATTENTION
 pgk_status flash_prefill_q8(const void* q, const void* k, const void* v, uint8_t* q8, float* q8s, int hq, int hkv, int q_len, int kv_len,
                             float scale, long long qh, long long qs, long long kh, long long ks, hipStream_t st);   // ops_flash.hip
+bool engine_gemm_qkv_heads_ok(int M, int N, int K);            // ops_gemm.hip: QKV projection with per-head norm + RoPE + cache write as its epilogue
+pgk_status engine_gemm_qkv_heads_nt(const bf16* A, const bf16* W, bf16* qkv, int M, int N, int K, const QkvHeadArgs& hd, hipStream_t st);
 bool engine_gemm_swiglu_ok(int M, int I, int K, bool fp8);     // ops_gemm.hip: gate / up projection with the SwiGLU epilogue
 pgk_status engine_gemm_swiglu_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, bf16* act, int M, int I, int K, hipStream_t st);
 bool gemm_fp8_swiglu_ok(int M, int I, int K);                  // ops_fp8_gemm.hip: ... and the e4m3 quantisation of the result
@@ -2366,6 +2369,8 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     // SwiGLU in the gate / up GEMM's epilogue (256-tile kernels; fp8 x fp8: with the quantisation of its result)
     const bool fuse_sw8 = fuse_q && gemm_fp8_swiglu_ok(n, I, H);
     const bool fuse_sw16 = !fp8act && !ws && fuse_epi && engine_gemm_swiglu_ok(n, I, H, fp8);
+    // per-head norm + RoPE + cache write in the QKV GEMM's epilogue (bf16 weights, head_dim 128, 128-tile kernel: tile column = head)
+    const bool fuse_heads = !ws && !pk && fuse_epi && c.weight_format == 0 && D == 128 && engine_gemm_qkv_heads_ok(n, NQKV, H);
     auto proj_accum = [&](const bf16* x_in, const void* w, const void* sc, int N_, int K_, int splits) -> pgk_status {
         if (fp8act) {
             if (x_in)
@@ -2426,10 +2431,17 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
             if (pgk_status r = pkgemm_nt(x, H, e->packed[l].qkv, qkv, NQKV, PK_EPI_QKV, 1, n, NQKV, H, &hd, st)) return r;
         } else if (pk) {
             if (pgk_status r = pkgemm_nt(x, H, e->packed[l].qkv, qkv, NQKV, PK_EPI_BF16, 1, n, NQKV, H, &nrm, st)) return r;
+        } else if (fuse_heads) {
+            QkvHeadArgs hd{};
+            hd.q_gamma = c.use_qk_norm ? (const bf16*)L.q_norm : nullptr;
+            hd.k_gamma = c.use_qk_norm ? (const bf16*)L.k_norm : nullptr;
+            hd.eps = c.norm_eps; hd.rope_cos = e->rope_cos; hd.rope_sin = e->rope_sin; hd.kcache = kc; hd.vcache = vc;
+            hd.hq = c.num_heads; hd.hkv = c.num_kv_heads; hd.max_seq = c.max_seq_len; hd.start_pos = start_pos;
+            if (pgk_status r = engine_gemm_qkv_heads_nt(x, (const bf16*)L.w_qkv, qkv, n, NQKV, H, hd, st)) return r;
         } else {
             if (pgk_status r = proj_store(fuse_q ? nullptr : x, L.w_qkv, L.s_qkv, qkv, NQKV, H, s_qkv)) return r;
         }
-        if (!pk_heads) {
+        if (!pk_heads && !fuse_heads) {
             const int s_qkv = pk ? 1 : s_qkv_ws;
             const int nslots = c.num_heads + 2 * c.num_kv_heads;
             const bf16* qg = c.use_qk_norm ? (const bf16*)L.q_norm : nullptr;

@@ -11,6 +11,7 @@
 // The reference reaches for CUTLASS / cuBLASLt here (native/ops/matmul/matmul.cu:43-354); neither
 // exists on this target and nothing is linked in their place.
 
+#include "gemm_epilogues.hip.h"
 #include "gemv_core.hip.h"
 #include "pgk_internal.h"
 
@@ -23,7 +24,8 @@ pgk_status gemm256_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void*
                            hipStream_t st);
 pgk_status gemm256_bf16_swiglu_nt(const bf16* A, const bf16* W, bf16* act, int M, int I, int K, hipStream_t st);
 bool gemm128s_ok(int M, int N, int K);    // ops_gemm256.hip: 128 x 128 tiles on the staged LDS-DMA pipeline (bf16, M > 128, K % 64 == 0, N % 8 == 0)
-pgk_status gemm128s_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, int mode, int splits, int M, int N, int K, hipStream_t st);
+pgk_status gemm128s_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, int mode, int splits, int M, int N, int K, hipStream_t st,
+                            const QkvHeadArgs* heads = nullptr);
 // the 256 x 256 structure needs enough tiles to fill the chip and whole 128-byte K rows
 // PGK_GEMM256 = 0 / 1 forces the choice (read per call: tests flip it to drive small shapes through both kernels); shared
 // with the fp8 x fp8 GEMM (ops_fp8_gemm.hip)
@@ -424,6 +426,15 @@ pgk_status engine_gemm_nt(const bf16* A, const void* W, const bf16* wscale, bool
     if (gemm128s_ok(M, N, K)) return gemm128s_bf16_nt(A, (const bf16*)W, nullptr, C, accum_f32 ? 1 : 0, 1, M, N, K, st);
     if (accum_f32) return dispatch_mfma<bf16, B_NT, 1>(A, W, nullptr, nullptr, C, M, N, K, st);
     return dispatch_mfma<bf16, B_NT, 0>(A, W, nullptr, nullptr, C, M, N, K, st);
+}
+
+// internal (engine prefill, bf16 weights, head_dim 128): the QKV projection with per-head RMSNorm + RoPE + KV-cache write as its
+// epilogue (QkvHeadArgs) - on the 128-tile kernel, whose tile columns are whole heads; where engine_gemm_nt would pick the
+// 256-tile kernel the separate pass stays
+bool engine_gemm_qkv_heads_ok(int M, int N, int K) { return N % 128 == 0 && gemm128s_ok(M, N, K) && !use_gemm256(M, N, K); }
+pgk_status engine_gemm_qkv_heads_nt(const bf16* A, const bf16* W, bf16* qkv, int M, int N, int K, const QkvHeadArgs& hd, hipStream_t st) {
+    PGK_REQUIRE(engine_gemm_qkv_heads_ok(M, N, K), "engine_gemm_qkv_heads: M=%d N=%d K=%d outside the fused kernel's shapes", M, N, K);
+    return gemm128s_bf16_nt(A, W, nullptr, qkv, 3, 1, M, N, K, st, &hd);
 }
 
 // internal (engine prefill): act[M][I] = bf16(silu(A . Wg^T) * (A . Wu^T)) on the fused [2 I, K] gate / up weight (bf16, or fp8 with

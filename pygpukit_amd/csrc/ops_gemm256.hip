@@ -16,6 +16,7 @@
 //
 // The reference calls CUTLASS / cuBLASLt here (native/ops/matmul/matmul.cu:142-235); nothing of theirs is used.
 
+#include "gemm_epilogues.hip.h"
 #include "gemv_core.hip.h"
 #include "pgk_internal.h"
 
@@ -421,9 +422,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A
 // back as rows - 32 lanes x 16 B = one 512-byte row segment per instruction - for coalesced stores (EPI 1: float4
 // read-modify-write of the residual stream, all loads issued before the first store).
 constexpr int G1_THREADS = 256, G1_HALF = 128 * 64;
-template <int EPI>   // 0: bf16 C store (+bias); 1: fp32 C +=; 2: fp32 split-K slab
+template <int EPI>   // 0: bf16 C store (+bias); 1: fp32 C +=; 2: fp32 split-K slab; 3: QKV heads (QkvHeadArgs: tile column = head slot)
 __global__ __launch_bounds__(G1_THREADS, 2) void gemm128s_bf16_kernel(const bf16* A, const bf16* W, const bf16* bias, void* Cv,
-                                                                       int M, int N, int K, int ntm, int ntn, int kps) {
+                                                                       int M, int N, int K, int ntm, int ntn, int kps, QkvHeadArgs hd) {
     extern __shared__ __attribute__((aligned(16))) char g2_smem[];   // 4 stages x (A 8 KiB | W 8 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1, q = lane >> 4, l15 = lane & 15;
@@ -505,7 +506,56 @@ __global__ __launch_bounds__(G1_THREADS, 2) void gemm128s_bf16_kernel(const bf16
                 *reinterpret_cast<float*>(g2_smem + row * 512 + (colb ^ (q << 6))) = acc[i][j][r];
             }
     __syncthreads();
-    if constexpr (EPI == 0) {
+    if constexpr (EPI == 3) {
+        // 16 consecutive lanes = one (token row, head): the arithmetic of qknorm_rope_kvwrite_kernel on the bf16-rounded row,
+        // so the result is bit-identical to GEMM (bf16 store) + that kernel.  Tile column tn is the head slot.
+        const bool is_q = tn < hd.hq, is_k = !is_q && tn < hd.hq + hd.hkv;
+        const bf16* gamma = is_q ? hd.q_gamma : hd.k_gamma;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int item = it * G1_THREADS + tid, row = item >> 4, c = item & 15, sw = ((row >> 2) & 3) << 6;
+            const float4 v0 = *reinterpret_cast<const float4*>(g2_smem + row * 512 + ((c * 32) ^ sw));
+            const float4 v1 = *reinterpret_cast<const float4*>(g2_smem + row * 512 + ((c * 32 + 16) ^ sw));
+            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            Vec<bf16> raw;
+            raw.from_float(f);
+            float x[8];
+            raw.to_float(x);
+            const int grow = m0 + row, pos = hd.start_pos + grow;
+            if (is_q || is_k) {        // workgroup-uniform
+                if (gamma) {
+                    float ss = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss = fmaf(x[j], x[j], ss);
+                    ss = group_sum<16>(ss);
+                    const float inv = 1.0f / sqrtf(ss / 128 + hd.eps);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = x[j] * inv * to_f(gamma[c * 8 + j]);
+                }
+                const bool lo = c < 8;
+                const float* cs = hd.rope_cos + (size_t)min(pos, hd.max_seq - 1) * 64;
+                const float* sn = hd.rope_sin + (size_t)min(pos, hd.max_seq - 1) * 64;
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float other = xor_half<16>(x[j]);
+                    const int dd = (c * 8 + j) % 64;
+                    o[j] = lo ? (x[j] * cs[dd] - other * sn[dd]) : (x[j] * cs[dd] + other * sn[dd]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = o[j];
+            }
+            if (grow >= M) continue;
+            Vec<bf16> ov;
+            ov.from_float(x);
+            if (is_q) {
+                ov.store(reinterpret_cast<bf16*>(Cv) + (size_t)grow * N + n0 + c * 8);
+            } else if (pos < hd.max_seq) {
+                const int kvh = is_k ? tn - hd.hq : tn - hd.hq - hd.hkv;
+                ov.store((is_k ? hd.kcache : hd.vcache) + ((size_t)kvh * hd.max_seq + pos) * 128 + c * 8);
+            }
+        }
+    } else if constexpr (EPI == 0) {
         // 8 columns per lane: two float4 -> 16 bytes of bf16
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -871,23 +921,28 @@ pgk_status gemm256_bf16_swiglu_nt(const bf16* A, const bf16* W, bf16* act, int M
 
 // 128 x 128 tiles; mode 0: bf16 C (+bias), 1: fp32 C +=, 2: fp32 slabs [splits][M][N] (K split into `splits` runs of whole 64-k steps)
 bool gemm128s_ok(int M, int N, int K) { return M > 128 && K % 64 == 0 && N % 8 == 0 && N >= 8; }
-pgk_status gemm128s_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, int mode, int splits, int M, int N, int K, hipStream_t st) {
-    PGK_REQUIRE(gemm128s_ok(M, N, K) && mode >= 0 && mode <= 2 && splits >= 1 && (splits == 1 || mode == 2), "gemm128s: M=%d N=%d K=%d mode=%d splits=%d", M, N, K, mode, splits);
+pgk_status gemm128s_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, int mode, int splits, int M, int N, int K, hipStream_t st,
+                            const QkvHeadArgs* heads) {
+    PGK_REQUIRE(gemm128s_ok(M, N, K) && mode >= 0 && mode <= 3 && splits >= 1 && (splits == 1 || mode == 2), "gemm128s: M=%d N=%d K=%d mode=%d splits=%d", M, N, K, mode, splits);
+    PGK_REQUIRE(mode != 3 || (heads && N == (heads->hq + 2 * heads->hkv) * 128), "gemm128s: the QKV-heads epilogue needs N=%d = (Hq + 2 Hkv) x 128", N);
+    const QkvHeadArgs hd = heads ? *heads : QkvHeadArgs{};
     constexpr size_t LDS = 8 * (size_t)G1_HALF;
     static bool attr_done = false;
     if (!attr_done) {
         PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128s_bf16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128s_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128s_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128s_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_done = true;
     }
     const int ntm = ceil_div(M, 128), ntn = ceil_div(N, 128);
     const int kps = ceil_div(ceil_div(K, splits), 64) * 64;
     const dim3 grid(ntm * ntn, ceil_div(K, kps));
     PGK_REQUIRE((int)grid.y == splits, "gemm128s: K=%d does not split into %d runs of whole 64-k steps", K, splits);
-    if (mode == 0) gemm128s_bf16_kernel<0><<<grid, G1_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn, kps);
-    else if (mode == 1) gemm128s_bf16_kernel<1><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps);
-    else gemm128s_bf16_kernel<2><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps);
+    if (mode == 0) gemm128s_bf16_kernel<0><<<grid, G1_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn, kps, hd);
+    else if (mode == 1) gemm128s_bf16_kernel<1><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd);
+    else if (mode == 2) gemm128s_bf16_kernel<2><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd);
+    else gemm128s_bf16_kernel<3><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd);
     PGK_CHECK_HIP(hipGetLastError());
     return PGK_OK;
 }

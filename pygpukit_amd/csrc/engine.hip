@@ -50,6 +50,9 @@ bool engine_gemm_qkv_heads_ok(int M, int N, int K);            // ops_gemm.hip: 
 pgk_status engine_gemm_qkv_heads_nt(const bf16* A, const bf16* W, bf16* qkv, int M, int N, int K, const QkvHeadArgs& hd, hipStream_t st);
 bool engine_gemm_swiglu_ok(int M, int I, int K, bool fp8);     // ops_gemm.hip: gate / up projection with the SwiGLU epilogue
 pgk_status engine_gemm_swiglu_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, bf16* act, int M, int I, int K, hipStream_t st);
+bool gemm_fp8_qkv_heads_ok(int M, int N, int K);               // ops_fp8_gemm.hip: the same epilogue on the fp8 x fp8 256-tile kernel
+pgk_status gemm_fp8_qkv_heads_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, bf16* qkv, int M, int N, int K,
+                                 const QkvHeadArgs& hd, hipStream_t st);
 bool gemm_fp8_swiglu_ok(int M, int I, int K);                  // ops_fp8_gemm.hip: ... and the e4m3 quantisation of the result
 pgk_status gemm_fp8_swiglu_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, uint8_t* q_out, float* s_out, int M, int I,
                               int K, hipStream_t st);
@@ -2370,7 +2373,8 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     const bool fuse_sw8 = fuse_q && gemm_fp8_swiglu_ok(n, I, H);
     const bool fuse_sw16 = !fp8act && !ws && fuse_epi && engine_gemm_swiglu_ok(n, I, H, fp8);
     // per-head norm + RoPE + cache write in the QKV GEMM's epilogue (bf16 weights, head_dim 128, 128-tile kernel: tile column = head)
-    const bool fuse_heads = !ws && !pk && fuse_epi && c.weight_format == 0 && D == 128 && engine_gemm_qkv_heads_ok(n, NQKV, H);
+    const bool fuse_heads8 = fuse_q && D == 128 && gemm_fp8_qkv_heads_ok(n, NQKV, H);      // fp8 x fp8: x's codes are already in q8
+    const bool fuse_heads = fuse_heads8 || (!ws && !pk && fuse_epi && c.weight_format == 0 && D == 128 && engine_gemm_qkv_heads_ok(n, NQKV, H));
     auto proj_accum = [&](const bf16* x_in, const void* w, const void* sc, int N_, int K_, int splits) -> pgk_status {
         if (fp8act) {
             if (x_in)
@@ -2437,7 +2441,9 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
             hd.k_gamma = c.use_qk_norm ? (const bf16*)L.k_norm : nullptr;
             hd.eps = c.norm_eps; hd.rope_cos = e->rope_cos; hd.rope_sin = e->rope_sin; hd.kcache = kc; hd.vcache = vc;
             hd.hq = c.num_heads; hd.hkv = c.num_kv_heads; hd.max_seq = c.max_seq_len; hd.start_pos = start_pos;
-            if (pgk_status r = engine_gemm_qkv_heads_nt(x, (const bf16*)L.w_qkv, qkv, n, NQKV, H, hd, st)) return r;
+            if (fuse_heads8) {
+                if (pgk_status r = gemm_fp8_qkv_heads_nt(q8, q8s, (const uint8_t*)L.w_qkv, (const bf16*)L.s_qkv, qkv, n, NQKV, H, hd, st)) return r;
+            } else if (pgk_status r = engine_gemm_qkv_heads_nt(x, (const bf16*)L.w_qkv, qkv, n, NQKV, H, hd, st)) return r;
         } else {
             if (pgk_status r = proj_store(fuse_q ? nullptr : x, L.w_qkv, L.s_qkv, qkv, NQKV, H, s_qkv)) return r;
         }

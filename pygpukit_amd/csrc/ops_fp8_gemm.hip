@@ -18,6 +18,7 @@
 // checkout: parity for this op is pinned on the oracle's restatement of the formula above).
 
 #include "gemv_core.hip.h"
+#include "gemm_epilogues.hip.h"
 #include "pgk_internal.h"
 
 namespace pgk {
@@ -212,6 +213,16 @@ pgk_status gemm256_fp8_nt(const uint8_t* a, const float* sa, const uint8_t* w, c
 pgk_status gemm256_fp8_swiglu_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, uint8_t* q_out, float* s_out, int M,
                                  int I, int K, hipStream_t st);
 bool want_gemm256(int M, int N);      // ops_gemm.hip
+
+pgk_status gemm256_fp8_qkv_heads_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, bf16* qkv, int M, int N, int K,
+                                    const QkvHeadArgs& hd, hipStream_t st);
+// QKV projection with per-head norm + RoPE + cache write as its epilogue (256-tile kernel: whole tiles, enough of them)
+bool gemm_fp8_qkv_heads_ok(int M, int N, int K) { return K % 128 == 0 && M % 256 == 0 && N % 256 == 0 && want_gemm256(M, N); }
+pgk_status gemm_fp8_qkv_heads_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, bf16* qkv, int M, int N, int K,
+                                 const QkvHeadArgs& hd, hipStream_t st) {
+    PGK_REQUIRE(gemm_fp8_qkv_heads_ok(M, N, K), "gemm_fp8_qkv_heads: M=%d N=%d K=%d outside the fused kernel's shapes", M, N, K);
+    return gemm256_fp8_qkv_heads_nt(a, sa, w, sw, qkv, M, N, K, hd, st);
+}
 
 // gate / up projection with the SwiGLU + e4m3 quantisation epilogue (ops_gemm256.hip): whole 256-row tiles, enough of them
 bool gemm_fp8_swiglu_ok(int M, int I, int K) { return K % 128 == 0 && I % 128 == 0 && M % 256 == 0 && want_gemm256(M, 2 * I); }

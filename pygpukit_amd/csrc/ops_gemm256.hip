@@ -163,6 +163,34 @@ __device__ __forceinline__ void g2_accum_epilogue(char* smem, const f32x4_g (&ac
     }
 }
 
+// ---- QKV-heads epilogue (EPI 3): the accumulators go to LDS as the bf16 tile the plain kernel would have stored (the layout of
+// g2_swiglu_epilogue), a tile = 256 token rows x two head slots, 16 consecutive lanes take one (row, head) and finish it
+// (qkv_head_finish: per-head RMSNorm, RoPE, q -> qkv buffer, k / v -> cache): bit-identical to GEMM + qknorm_rope_kvwrite_kernel.
+__device__ __forceinline__ void g2_qkv_heads_epilogue(char* smem, const f32x4_g (&acc)[8][4], int tid, int m0, int tn, int M, int N, bf16* qkv,
+                                                      const QkvHeadArgs& hd) {
+    const int lane = tid & 63, wid = tid >> 6, wr = wid >> 2, wc = wid & 3, q = lane >> 4, l15 = lane & 15;
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr * 128 + i * 16 + q * 4 + r, colb = (wc * 64 + j * 16 + l15) * 2;
+                *reinterpret_cast<bf16*>(smem + row * 512 + (colb ^ (q << 5))) = from_f<bf16>(acc[i][j][r]);
+            }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int item = it * G2_THREADS + tid, row = item >> 5, c = item & 31, sw = ((row >> 2) & 3) << 5;
+        Vec<bf16> raw;
+        raw.raw = *reinterpret_cast<const uint4*>(smem + row * 512 + ((c * 16) ^ sw));
+        float x[8];
+        raw.to_float(x);
+        qkv_head_finish(x, c & 15, 2 * tn + (c >> 4), m0 + row, M, hd, qkv, N);
+    }
+}
+
 template <int EPI>   // 0: bf16 C store (+bias); 1: fp32 C +=
 __global__ __launch_bounds__(G2_THREADS) void gemm256_bf16_kernel(const bf16* A, const bf16* W, const bf16* bias, void* Cv,
                                                                    int M, int N, int K, int ntm, int ntn) {
@@ -509,8 +537,6 @@ __global__ __launch_bounds__(G1_THREADS, 2) void gemm128s_bf16_kernel(const bf16
     if constexpr (EPI == 3) {
         // 16 consecutive lanes = one (token row, head): the arithmetic of qknorm_rope_kvwrite_kernel on the bf16-rounded row,
         // so the result is bit-identical to GEMM (bf16 store) + that kernel.  Tile column tn is the head slot.
-        const bool is_q = tn < hd.hq, is_k = !is_q && tn < hd.hq + hd.hkv;
-        const bf16* gamma = is_q ? hd.q_gamma : hd.k_gamma;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int item = it * G1_THREADS + tid, row = item >> 4, c = item & 15, sw = ((row >> 2) & 3) << 6;
@@ -521,39 +547,7 @@ __global__ __launch_bounds__(G1_THREADS, 2) void gemm128s_bf16_kernel(const bf16
             raw.from_float(f);
             float x[8];
             raw.to_float(x);
-            const int grow = m0 + row, pos = hd.start_pos + grow;
-            if (is_q || is_k) {        // workgroup-uniform
-                if (gamma) {
-                    float ss = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) ss = fmaf(x[j], x[j], ss);
-                    ss = group_sum<16>(ss);
-                    const float inv = 1.0f / sqrtf(ss / 128 + hd.eps);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = x[j] * inv * to_f(gamma[c * 8 + j]);
-                }
-                const bool lo = c < 8;
-                const float* cs = hd.rope_cos + (size_t)min(pos, hd.max_seq - 1) * 64;
-                const float* sn = hd.rope_sin + (size_t)min(pos, hd.max_seq - 1) * 64;
-                float o[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float other = xor_half<16>(x[j]);
-                    const int dd = (c * 8 + j) % 64;
-                    o[j] = lo ? (x[j] * cs[dd] - other * sn[dd]) : (x[j] * cs[dd] + other * sn[dd]);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = o[j];
-            }
-            if (grow >= M) continue;
-            Vec<bf16> ov;
-            ov.from_float(x);
-            if (is_q) {
-                ov.store(reinterpret_cast<bf16*>(Cv) + (size_t)grow * N + n0 + c * 8);
-            } else if (pos < hd.max_seq) {
-                const int kvh = is_k ? tn - hd.hq : tn - hd.hq - hd.hkv;
-                ov.store((is_k ? hd.kcache : hd.vcache) + ((size_t)kvh * hd.max_seq + pos) * 128 + c * 8);
-            }
+            qkv_head_finish(x, c, tn, m0 + row, M, hd, reinterpret_cast<bf16*>(Cv), N);
         }
     } else if constexpr (EPI == 0) {
         // 8 columns per lane: two float4 -> 16 bytes of bf16
@@ -617,9 +611,10 @@ __device__ __forceinline__ void g2_dma2_so(const void* sbase, uint32_t voff, uin
 
 constexpr int G2_SCALE_BYTES = 256 * 4 + 256;   // per buffer: 256 fp32 row scales | 64 lanes x 4 B of weight-scale slots (2 used)
 
-template <int EPI>   // 0: bf16 C store; 1: fp32 C +=; 2: SwiGLU + e4m3 quantisation (W = fused gate / up rows, N = I; Cv = codes [M][I], Cs = scales [M][I/128])
+template <int EPI>   // 0: bf16 C store; 1: fp32 C +=; 2: SwiGLU + e4m3 quantisation (W = fused gate / up rows, N = I; Cv = codes [M][I], Cs = scales [M][I/128]);
+                     // 3: QKV heads (QkvHeadArgs; a tile holds two head slots)
 __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* A, const float* sa, const uint8_t* W, const bf16* sw,
-                                                                  void* Cv, float* Cs, int M, int N, int K, int ntm, int ntn) {
+                                                                  void* Cv, float* Cs, int M, int N, int K, int ntm, int ntn, QkvHeadArgs hd) {
     extern __shared__ __attribute__((aligned(16))) char g2_smem[];   // A[2] | W[2] | scales[2]
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // in an SGPR: it enters the DMAs' scalar bases
     const int wr = wid >> 2, wc = wid & 3, q = lane >> 4, l15 = lane & 15;
@@ -812,6 +807,10 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_fp8_kernel(const uint8_t* 
         g2_accum_epilogue(g2_smem, acc, tid, m0, n0, M, N, reinterpret_cast<float*>(Cv));
         return;
     }
+    if constexpr (EPI == 3) {
+        g2_qkv_heads_epilogue(g2_smem, acc, tid, m0, tn, M, N, reinterpret_cast<bf16*>(Cv), hd);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = n0 + wc * 64 + j * 16 + l15;
@@ -839,8 +838,25 @@ pgk_status gemm256_fp8_nt(const uint8_t* a, const float* sa, const uint8_t* w, c
         attr_done = true;
     }
     const int ntm = ceil_div(M, G2_BM), ntn = ceil_div(N, G2_BN);
-    if (accum_f32) gemm256_fp8_kernel<1><<<ntm * ntn, G2_THREADS, LDS, st>>>(a, sa, w, sw, c, nullptr, M, N, K, ntm, ntn);
-    else gemm256_fp8_kernel<0><<<ntm * ntn, G2_THREADS, LDS, st>>>(a, sa, w, sw, c, nullptr, M, N, K, ntm, ntn);
+    if (accum_f32) gemm256_fp8_kernel<1><<<ntm * ntn, G2_THREADS, LDS, st>>>(a, sa, w, sw, c, nullptr, M, N, K, ntm, ntn, QkvHeadArgs{});
+    else gemm256_fp8_kernel<0><<<ntm * ntn, G2_THREADS, LDS, st>>>(a, sa, w, sw, c, nullptr, M, N, K, ntm, ntn, QkvHeadArgs{});
+    PGK_CHECK_HIP(hipGetLastError());
+    return PGK_OK;
+}
+
+// QKV projection finished per head in the epilogue (QkvHeadArgs): N = (Hq + 2 Hkv) x 128, two head slots per tile
+pgk_status gemm256_fp8_qkv_heads_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, bf16* qkv, int M, int N, int K,
+                                    const QkvHeadArgs& hd, hipStream_t st) {
+    PGK_REQUIRE(K % 128 == 0 && K >= 128 && M % G2_BM == 0 && N % G2_BN == 0 && N == (hd.hq + 2 * hd.hkv) * 128,
+                "gemm256 fp8 qkv heads: M=%d, N=%d must be multiples of 256, K=%d of 128, N = (Hq + 2 Hkv) x 128", M, N, K);
+    constexpr size_t LDS = 4 * (size_t)G2_TILE + 2 * G2_SCALE_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_fp8_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        attr_done = true;
+    }
+    const int ntm = M / G2_BM, ntn = N / G2_BN;
+    gemm256_fp8_kernel<3><<<ntm * ntn, G2_THREADS, LDS, st>>>(a, sa, w, sw, qkv, nullptr, M, N, K, ntm, ntn, hd);
     PGK_CHECK_HIP(hipGetLastError());
     return PGK_OK;
 }
@@ -857,7 +873,7 @@ pgk_status gemm256_fp8_swiglu_nt(const uint8_t* a, const float* sa, const uint8_
         attr_done = true;
     }
     const int ntm = M / G2_BM, ntn = I / 128;
-    gemm256_fp8_kernel<2><<<ntm * ntn, G2_THREADS, LDS, st>>>(a, sa, w, sw, q_out, s_out, M, I, K, ntm, ntn);
+    gemm256_fp8_kernel<2><<<ntm * ntn, G2_THREADS, LDS, st>>>(a, sa, w, sw, q_out, s_out, M, I, K, ntm, ntn, QkvHeadArgs{});
     PGK_CHECK_HIP(hipGetLastError());
     return PGK_OK;
 }

@@ -440,9 +440,14 @@ pgk_status engine_gemm_qkv_heads_nt(const bf16* A, const bf16* W, bf16* qkv, int
 // internal (engine prefill): act[M][I] = bf16(silu(A . Wg^T) * (A . Wu^T)) on the fused [2 I, K] gate / up weight (bf16, or fp8 with
 // block scales: dequantised once into a bf16 scratch as in engine_gemm_nt), SwiGLU in the 256-tile kernel's epilogue - the
 // [M][2 I] intermediate never goes to HBM.  Only where engine_gemm_nt would pick the 256-tile kernel anyway.
-bool engine_gemm_swiglu_ok(int M, int I, int K, bool fp8) { return I % 128 == 0 && use_gemm256(M, 2 * I, K) && (!fp8 || K % 128 == 0); }
+// (below 192 tiles of 256 x 256, bf16 weights: the same epilogue on the 128-tile kernel, 64 gate + 64 up rows per tile)
+bool engine_gemm_swiglu_ok(int M, int I, int K, bool fp8) {
+    if (I % 128 == 0 && use_gemm256(M, 2 * I, K) && (!fp8 || K % 128 == 0)) return true;
+    return !fp8 && I % 64 == 0 && gemm128s_ok(M, I, K);
+}
 pgk_status engine_gemm_swiglu_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, bf16* act, int M, int I, int K, hipStream_t st) {
     PGK_REQUIRE(engine_gemm_swiglu_ok(M, I, K, fp8), "engine_gemm_swiglu: M=%d I=%d K=%d outside the fused kernel's shapes", M, I, K);
+    if (!(I % 128 == 0 && use_gemm256(M, 2 * I, K))) return gemm128s_bf16_nt(A, (const bf16*)W, nullptr, act, 4, 1, M, I, K, st);
     if (!fp8) return gemm256_bf16_swiglu_nt(A, (const bf16*)W, act, M, I, K, st);
     void* wb = nullptr;
     if (pgk_status r = pgk_malloc(&wb, (size_t)2 * I * K * sizeof(bf16))) return r;

@@ -450,7 +450,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A
 // back as rows - 32 lanes x 16 B = one 512-byte row segment per instruction - for coalesced stores (EPI 1: float4
 // read-modify-write of the residual stream, all loads issued before the first store).
 constexpr int G1_THREADS = 256, G1_HALF = 128 * 64;
-template <int EPI>   // 0: bf16 C store (+bias); 1: fp32 C +=; 2: fp32 split-K slab; 3: QKV heads (QkvHeadArgs: tile column = head slot)
+template <int EPI>   // 0: bf16 C store (+bias); 1: fp32 C +=; 2: fp32 split-K slab; 3: QKV heads (QkvHeadArgs: tile column = head slot);
+                     // 4: SwiGLU (W = fused gate / up rows, N = I act columns, C = bf16 act [M][I]; tile tn = act columns [64 tn, +64))
 __global__ __launch_bounds__(G1_THREADS, 2) void gemm128s_bf16_kernel(const bf16* A, const bf16* W, const bf16* bias, void* Cv,
                                                                        int M, int N, int K, int ntm, int ntn, int kps, QkvHeadArgs hd) {
     extern __shared__ __attribute__((aligned(16))) char g2_smem[];   // 4 stages x (A 8 KiB | W 8 KiB)
@@ -465,8 +466,11 @@ __global__ __launch_bounds__(G1_THREADS, 2) void gemm128s_bf16_kernel(const bf16
     const int dchunk = (lane & 3) ^ ((lane >> 4) & 2);
     const bf16* a_src0 = A + (size_t)min(m0 + drow, M - 1) * K + kbeg + dchunk * 8;
     const bf16* a_src1 = A + (size_t)min(m0 + drow + 16, M - 1) * K + kbeg + dchunk * 8;
-    const bf16* w_src0 = W + (size_t)min(n0 + drow, N - 1) * K + kbeg + dchunk * 8;
-    const bf16* w_src1 = W + (size_t)min(n0 + drow + 16, N - 1) * K + kbeg + dchunk * 8;
+    // EPI 4: B-tile rows 0-63 = gate rows 64 tn .., rows 64-127 = the matching up rows N + 64 tn .. (N = I); a wave's 32 rows stay in one half
+    const int wrow = (EPI == 4) ? (drow < 64 ? tn * 64 + drow : N + tn * 64 + drow - 64) : n0 + drow;
+    const int wlast = (EPI == 4) ? 2 * N - 1 : N - 1;
+    const bf16* w_src0 = W + (size_t)min(wrow, wlast) * K + kbeg + dchunk * 8;
+    const bf16* w_src1 = W + (size_t)min(wrow + 16, wlast) * K + kbeg + dchunk * 8;
     const uint32_t lds0 = g2_lds_addr(g2_smem);
     const int nh = (kend - kbeg) / 32;
     auto stage = [&](int h, int buf) {
@@ -534,7 +538,28 @@ __global__ __launch_bounds__(G1_THREADS, 2) void gemm128s_bf16_kernel(const bf16
                 *reinterpret_cast<float*>(g2_smem + row * 512 + (colb ^ (q << 6))) = acc[i][j][r];
             }
     __syncthreads();
-    if constexpr (EPI == 3) {
+    if constexpr (EPI == 4) {
+        // act = bf16(silu(g) * u) from the bf16-rounded g and u (the arithmetic of swiglu_rows_kernel / g2_swiglu_epilogue): 8 lanes per row
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = it * G1_THREADS + tid, row = item >> 3, c = item & 7, sw = ((row >> 2) & 3) << 6;
+            const char* rp = g2_smem + row * 512;
+            const float4 g0 = *reinterpret_cast<const float4*>(rp + ((c * 32) ^ sw)), g1 = *reinterpret_cast<const float4*>(rp + ((c * 32 + 16) ^ sw));
+            const float4 u0 = *reinterpret_cast<const float4*>(rp + ((256 + c * 32) ^ sw)), u1 = *reinterpret_cast<const float4*>(rp + ((256 + c * 32 + 16) ^ sw));
+            const float gfr[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, ufr[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+            Vec<bf16> g, u;
+            g.from_float(gfr);
+            u.from_float(ufr);
+            float gf[8], uf[8];
+            g.to_float(gf);
+            u.to_float(uf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gf[e] = gf[e] / (1.0f + __expf(-gf[e])) * uf[e];
+            g.from_float(gf);
+            const int grow = m0 + row, gcol = tn * 64 + c * 8;
+            if (grow < M && gcol < N) g.store(reinterpret_cast<bf16*>(Cv) + (size_t)grow * N + gcol);
+        }
+    } else if constexpr (EPI == 3) {
         // 16 consecutive lanes = one (token row, head): the arithmetic of qknorm_rope_kvwrite_kernel on the bf16-rounded row,
         // so the result is bit-identical to GEMM (bf16 store) + that kernel.  Tile column tn is the head slot.
 #pragma unroll
@@ -939,7 +964,8 @@ pgk_status gemm256_bf16_swiglu_nt(const bf16* A, const bf16* W, bf16* act, int M
 bool gemm128s_ok(int M, int N, int K) { return M > 128 && K % 64 == 0 && N % 8 == 0 && N >= 8; }
 pgk_status gemm128s_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, int mode, int splits, int M, int N, int K, hipStream_t st,
                             const QkvHeadArgs* heads) {
-    PGK_REQUIRE(gemm128s_ok(M, N, K) && mode >= 0 && mode <= 3 && splits >= 1 && (splits == 1 || mode == 2), "gemm128s: M=%d N=%d K=%d mode=%d splits=%d", M, N, K, mode, splits);
+    PGK_REQUIRE(gemm128s_ok(M, N, K) && mode >= 0 && mode <= 4 && splits >= 1 && (splits == 1 || mode == 2), "gemm128s: M=%d N=%d K=%d mode=%d splits=%d", M, N, K, mode, splits);
+    PGK_REQUIRE(mode != 4 || N % 64 == 0, "gemm128s: the SwiGLU epilogue needs I=%d to be a multiple of 64", N);
     PGK_REQUIRE(mode != 3 || (heads && N == (heads->hq + 2 * heads->hkv) * 128), "gemm128s: the QKV-heads epilogue needs N=%d = (Hq + 2 Hkv) x 128", N);
     const QkvHeadArgs hd = heads ? *heads : QkvHeadArgs{};
     constexpr size_t LDS = 8 * (size_t)G1_HALF;
@@ -949,16 +975,18 @@ pgk_status gemm128s_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void
         PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128s_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128s_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128s_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128s_bf16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_done = true;
     }
-    const int ntm = ceil_div(M, 128), ntn = ceil_div(N, 128);
+    const int ntm = ceil_div(M, 128), ntn = mode == 4 ? N / 64 : ceil_div(N, 128);      // SwiGLU: N = I act columns, 64 per tile
     const int kps = ceil_div(ceil_div(K, splits), 64) * 64;
     const dim3 grid(ntm * ntn, ceil_div(K, kps));
     PGK_REQUIRE((int)grid.y == splits, "gemm128s: K=%d does not split into %d runs of whole 64-k steps", K, splits);
     if (mode == 0) gemm128s_bf16_kernel<0><<<grid, G1_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn, kps, hd);
     else if (mode == 1) gemm128s_bf16_kernel<1><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd);
     else if (mode == 2) gemm128s_bf16_kernel<2><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd);
-    else gemm128s_bf16_kernel<3><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd);
+    else if (mode == 3) gemm128s_bf16_kernel<3><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd);
+    else gemm128s_bf16_kernel<4><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd);
     PGK_CHECK_HIP(hipGetLastError());
     return PGK_OK;
 }

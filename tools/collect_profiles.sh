@@ -45,6 +45,7 @@ else
   echo "== part 2" | tee -a $O/progress.log
   stats prefill128 $R/tools/prefill_prof.py 128 20
   stats prefill2048 $R/tools/prefill_prof.py 2048 5
+  stats prefill512 $R/tools/prefill_prof.py 512 10
   stats config5_L4 $R/tools/config5_prefill.py 4096 4 2
   timeout -k 10 400 python tools/config5_prefill.py 4096 32 3 > $O/config5_prefill.log 2>&1 || echo "config5 L32 failed" | tee -a $O/progress.log
   timeout -k 10 200 python tools/gemm_bench.py bf16 4096 4096 4096 8192 8192 8192 4096 6144 4096 4096 28672 4096 4096 4096 14336 2048 1024 2048 2048 1024 3072 2048 4096 1024 2048 6144 1024 > $O/gemm_bench.log 2>&1 || echo "gemm bf16 failed" | tee -a $O/progress.log

@@ -668,7 +668,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(unsigned long long* tl
         // are loaded from clamped addresses BEFORE the position is known, so the K/V bytes, the q/k/v row and the
         // position share one memory round trip (the split path below learns the position first, then walks:
         // two dependent trips - 9.2 us against 6.x for 8 sequences).
-        constexpr int U0 = 12;
+        // The position-independent part is the first 128 rows; rows 128-191 are requested as soon as the position is there
+        // (a scalar load that overtakes the vector loads in flight), clamped to the LAST CACHED ROW instead of the cache's
+        // last row: with 64 sequences at context ~150 every workgroup used to pull 192 rows whatever the context - 50 MB per
+        // layer for 39 MB of live K/V, and this kernel is bandwidth-bound at that batch (3.2 TB/s of live bytes).
+        constexpr int U0 = 8, UB = 4;
         NewTokenRaw<G> raw;                 // issue order = arrival order: the few L2-resident q/k/v bytes first, then the K/V rows
         new_token_load<D, G>(a, b, kvh, lane, raw);
         __builtin_amdgcn_sched_barrier(0);
@@ -676,6 +680,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(unsigned long long* tl
         kv_issue<D, U0, 4>(kb0, a.kcache + head_off, a.vcache + head_off, wid * PPW, a.max_seq - 1, lane);
         __builtin_amdgcn_sched_barrier(0);
         const int pos = load_uniform_i32(a.positions + b);   // scalar path (pgk_device.hip.h): not queued behind the vector loads in flight
+        const int c1 = min(pos, a.max_seq);
+        KVBatch<UB> kb1;
+        kv_issue<D, UB, 4>(kb1, a.kcache + head_off, a.vcache + head_off, U0 * 4 * PPW + wid * PPW, max(c1 - 1, 0), lane);
+        __builtin_amdgcn_sched_barrier(0);
         NewToken<D, G> t;
         new_token_finish<D, G>(a, lane, raw, t);
         if (pos < a.max_seq && wid == 0 && lane < LPR && a.g_off == 0) {
@@ -684,9 +692,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(unsigned long long* tl
         }
         DecodeState<G> st;
         st.init();
-        const int c1 = min(pos, a.max_seq);
         kv_consume<D, G, U0, 4>(kb0, wid * PPW, c1, t.qb, lane, st);
-        if (c1 > U0 * 4 * PPW) decode_walk_trips<D, G>(a.kcache + head_off, a.vcache + head_off, U0 * 4 * PPW, c1, t.qb, lane, wid, st);
+        kv_consume<D, G, UB, 4>(kb1, U0 * 4 * PPW + wid * PPW, c1, t.qb, lane, st);
+        if (c1 > (U0 + UB) * 4 * PPW) decode_walk_trips<D, G>(a.kcache + head_off, a.vcache + head_off, (U0 + UB) * 4 * PPW, c1, t.qb, lane, wid, st);
         if (pos < a.max_seq && wid == 0 && lane < LPR) fold_new_token<D, G>(t, st);
         decode_block_merge_lds<D, G>(st, lds, attn_out, lane, wid);
         if (a.attn_direct16) {

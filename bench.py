@@ -153,12 +153,18 @@ def main() -> None:
     if cp.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={cp.world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     ndev = _hip.device_count()
-    _hip.call("pgk_device_set", cp.local_rank % max(ndev, 1))
+    my_device = cp.local_rank % max(ndev, 1)
+    _hip.call("pgk_device_set", my_device)
+    if os.environ.get("PGK_REHEARSE_SHARED_GPU") == "1":
+        # rehearsal on a box with fewer GPUs than ranks (tools/rehearse_n2.sh): the ranks share devices, so the launcher
+        # rendezvous, the RCCL id exchange and communicator bring-up (or its refusal of a duplicate GPU -> exit 3 on every
+        # rank) run with real processes.  The number such a run prints is NOT a scaling measurement.
+        ndev = max(ndev, cp.world)
     # RCCL carries the one-time weight broadcast and the end-of-run token gather.  For N > 1 it is mandatory: a run
     # whose communicator does not come up prints the reason and exits non-zero instead of reporting a number that no
     # RCCL traffic stands behind (parallel.open_comm: every rank takes the same branch).
     try:
-        comm = DP.open_comm(cp, ndev, RcclComm)
+        comm = DP.open_comm(cp, ndev, lambda cp_: RcclComm(cp_, device=my_device))
     except DP.CommUnavailable as e:
         if cp.rank == 0:
             print(json.dumps({"error": "RCCL is mandatory for --gpus > 1 and did not come up", "detail": str(e), "n_gpus": cp.world}))

@@ -196,38 +196,41 @@ class ControlPlane:
             else:
                 self._plane = _SocketPlane(self.rank, self.world)
 
-    def all_gather_object(self, item) -> list:
-        """Every rank's (picklable) item in rank order."""
+    def all_gather_object(self, item, tag: str = "obj") -> list:
+        """Every rank's (picklable) item in rank order.  `tag` names the collective: ranks that meet in DIFFERENT collectives
+        (one rank took an error path the others did not) get a RuntimeError that says so, instead of each other's payloads."""
         if self._plane is not None:
-            return self._plane.all_gather(item)
-        if self._dist is not None:
-            outs = [None] * self.world
-            self._dist.all_gather_object(outs, item)
-            return outs
-        return [item]
+            pairs = self._plane.all_gather((tag, item))
+        elif self._dist is not None:
+            pairs = [None] * self.world
+            self._dist.all_gather_object(pairs, (tag, item))
+        else:
+            return [item]
+        tags = [t for t, _ in pairs]
+        if any(t != tag for t in tags):
+            raise RuntimeError(f"control plane: the ranks are in different collectives {tags} (rank {self.rank} is in {tag!r})")
+        return [v for _, v in pairs]
 
     def barrier(self) -> None:
-        if self._plane is not None:
-            self._plane.all_gather(None)
-        elif self._dist is not None:
-            self._dist.barrier()
+        if self._plane is not None or self._dist is not None:
+            self.all_gather_object(None, "barrier")
 
     def max_over_ranks(self, value: float) -> float:
-        return float(max(self.all_gather_object(float(value))))
+        return float(max(self.all_gather_object(float(value), "max")))
 
     def min_over_ranks(self, value: float) -> float:
-        return float(min(self.all_gather_object(float(value))))
+        return float(min(self.all_gather_object(float(value), "min")))
 
     def sum_over_ranks(self, value: float) -> float:
-        return float(sum(self.all_gather_object(float(value))))
+        return float(sum(self.all_gather_object(float(value), "sum")))
 
     def first_note(self, note: str | None) -> str | None:
         """The first non-empty string any rank holds (rank order) - used to report one rank's error on rank 0."""
-        return next((o for o in self.all_gather_object(note) if o), None)
+        return next((o for o in self.all_gather_object(note, "note") if o), None)
 
     def broadcast_bytes(self, data: bytes | None, n: int, root: int = 0) -> bytes:
         """Broadcast an n-byte blob from root (used for the 128-byte RCCL unique id)."""
-        blob = self.all_gather_object(bytes(data) if self.rank == root else None)[root]
+        blob = self.all_gather_object(bytes(data) if self.rank == root else None, "bytes")[root]
         if len(blob) != n:
             raise ValueError(f"broadcast_bytes: root sent {len(blob)} bytes, expected {n}")
         return blob
@@ -235,7 +238,7 @@ class ControlPlane:
     def gather_int32(self, local: np.ndarray) -> np.ndarray:
         """All-gather equal-length int32 vectors over the control plane (CPU test path; RCCL carries them on GPUs)."""
         local = np.ascontiguousarray(local, dtype=np.int32)
-        parts = self.all_gather_object(local.tobytes())
+        parts = self.all_gather_object(local.tobytes(), "int32")
         if any(len(p) != local.nbytes for p in parts):
             raise ValueError("gather_int32: ranks sent vectors of different length")
         return np.stack([np.frombuffer(p, dtype=np.int32) for p in parts])
@@ -255,28 +258,38 @@ class ControlPlane:
 
 
 class RcclComm:
-    """RCCL communicator over the C ABI (pgk_comm_*): one per process, device = LOCAL_RANK."""
+    """RCCL communicator over the C ABI (pgk_comm_*): one per process, device = LOCAL_RANK unless `device` says otherwise.
 
-    def __init__(self, cp: ControlPlane):
-        from pygpukit_amd import _hip
+    Bring-up runs in phases whose control-plane collectives EVERY rank enters whatever happened to it locally, and nobody
+    enters the communicator's own rendezvous (ncclCommInitRank blocks until all ranks arrive) unless every rank got that far:
+    (1) select the device, rank 0 draws the unique id; (2) id broadcast + "did everyone get here" vote - a rank whose device
+    or id failed votes no, and then every rank raises the first failing rank's reason; (3) pgk_comm_init.
+    (`hip` is the C-ABI module; the CPU tests pass a stand-in to drive the failure branches at world 2.)"""
 
-        self._hip = _hip
+    def __init__(self, cp: ControlPlane, device: int | None = None, hip=None):
+        if hip is None:
+            from pygpukit_amd import _hip as hip
+        self._hip = hip
         self.cp = cp
-        _hip.call("pgk_device_set", cp.local_rank)
+        self._h = 0
         uid, err = None, None
-        if cp.rank == 0:
-            # a failure here must not skip the broadcast below (the other ranks are already waiting in it)
-            try:
+        try:
+            hip.call("pgk_device_set", cp.local_rank if device is None else device)
+            if cp.rank == 0:
                 buf = C.create_string_buffer(128)
-                _hip.call("pgk_comm_unique_id", buf)
+                hip.call("pgk_comm_unique_id", buf)
                 uid = buf.raw
-            except Exception as e:  # noqa: BLE001
-                uid, err = bytes(128), e
-        uid = cp.broadcast_bytes(uid, 128, 0)
-        if uid == bytes(128):
-            raise RuntimeError(f"RCCL unique id could not be created on rank 0: {err}")
+        except Exception as e:  # noqa: BLE001
+            err = f"rank {cp.rank}: {type(e).__name__}: {e}"
+        uid = cp.broadcast_bytes(uid if uid is not None else bytes(128), 128, 0)
+        if err is None and uid == bytes(128):
+            err = "rank 0 could not create the RCCL unique id" if cp.rank == 0 else None
+        everyone = cp.min_over_ranks(0 if (err is not None or uid == bytes(128)) else 1)
+        first = cp.first_note(err)
+        if everyone == 0:
+            raise RuntimeError(f"RCCL bring-up stopped before the rendezvous: {first or 'a rank failed'}")
         h = C.c_void_p()
-        _hip.call("pgk_comm_init", C.byref(h), uid, cp.rank, cp.world)
+        hip.call("pgk_comm_init", C.byref(h), uid, cp.rank, cp.world)
         self._h = h.value
 
     def broadcast(self, arr, root: int = 0) -> None:

@@ -291,6 +291,67 @@ def test_bench_without_a_communicator_on_one_rank_fails_on_every_rank(tmp_path):
     mp.spawn(_bench_worker, args=(2, _free_port(), str(tmp_path), "socket", 1), nprocs=2, join=True)
 
 
+class _FakeHip:
+    """Stand-in for pygpukit_amd._hip in RcclComm: records the calls, fails the named entry point on the named rank."""
+
+    def __init__(self, rank, fail_rank, fail_call):
+        self.rank, self.fail_rank, self.fail_call, self.calls = rank, fail_rank, fail_call, []
+
+    def call(self, name, *args):
+        self.calls.append(name)
+        if self.rank == self.fail_rank and name == self.fail_call:
+            raise RuntimeError(f"{name} failed here")
+        if name == "pgk_comm_unique_id":
+            args[0].raw = bytes(range(1, 129))
+        if name == "pgk_comm_init":
+            self.uid = bytes(args[1])
+            args[0]._obj.value = 4242
+
+
+def _bringup_worker(rank: int, world: int, port: int, out_dir: str, fail_rank: int, fail_call: str) -> None:
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      PGK_CP_DIR=out_dir)
+    from pygpukit_amd import parallel as DP
+
+    cp = DP.ControlPlane("socket")
+    hip = _FakeHip(rank, fail_rank, fail_call)
+    make = lambda cp_: DP.RcclComm(cp_, hip=hip)   # noqa: E731
+    if fail_rank < 0:
+        comm = DP.open_comm(cp, world, make)
+        assert comm._h == 4242 and hip.uid == bytes(range(1, 129))          # every rank initialised with rank 0's id
+        assert hip.calls == (["pgk_device_set", "pgk_comm_unique_id", "pgk_comm_init"] if rank == 0 else ["pgk_device_set", "pgk_comm_init"])
+    elif fail_call == "pgk_comm_init":
+        # past the vote: the failing rank raises inside the rendezvous call, open_comm's own vote reports it everywhere
+        with pytest.raises(DP.CommUnavailable, match=f"rank {fail_rank}: RuntimeError: pgk_comm_init failed here"):
+            DP.open_comm(cp, world, make)
+    else:
+        # before the rendezvous: EVERY rank stops with the failing rank's reason and NOBODY calls pgk_comm_init
+        # (ncclCommInitRank would block the healthy ranks until the missing one arrives)
+        with pytest.raises(DP.CommUnavailable, match=f"rank {fail_rank}: RuntimeError: {fail_call} failed here"):
+            DP.open_comm(cp, world, make)
+        assert "pgk_comm_init" not in hip.calls
+    # ranks that meet in different collectives are told so
+    if rank == 0:
+        with pytest.raises(RuntimeError, match="different collectives"):
+            cp.max_over_ranks(1.0)
+    else:
+        with pytest.raises(RuntimeError, match="different collectives"):
+            cp.min_over_ranks(1.0)
+    cp.barrier()
+    cp.shutdown()
+
+
+@pytest.mark.parametrize("fail_rank,fail_call", [(-1, ""), (1, "pgk_device_set"), (0, "pgk_comm_unique_id"), (1, "pgk_comm_init")])
+def test_rccl_bring_up_phases_at_world_2(fail_rank, fail_call, tmp_path):
+    """RcclComm's bring-up with the C ABI replaced by a recorder, two real processes on the socket control plane: a rank that
+    fails BEFORE the communicator's rendezvous (no device, no unique id) must not leave the others in a different collective or
+    inside ncclCommInitRank - found by rehearsing `bench.py --gpus 2` on a one-GPU box, where rank 1's device does not exist."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_bringup_worker, args=(2, _free_port(), str(tmp_path), fail_rank, fail_call), nprocs=2, join=True)
+
+
 def test_expected_strong_scaling_from_the_n1_legs():
     sys.path.insert(0, ROOT)
     from pygpukit_amd.parallel import expected_config4_efficiency

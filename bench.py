@@ -140,6 +140,16 @@ def main() -> None:
     ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (result is then INVALID)")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout, whatever the libraries underneath print: RCCL writes a version banner to the process's stdout
+    # during communicator bring-up (seen in the two-rank rehearsal, profiles/r03_n2_rehearsal.txt).  File descriptor 1 is
+    # pointed at stderr for the run; the result line goes to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj) -> None:
+        os.write(result_fd, (json.dumps(obj) + "\n").encode())
+
     from pygpukit_amd import _hip
     from pygpukit_amd.core.array import GPUArray
     from pygpukit_amd.core.dtypes import bfloat16, int32, uint8
@@ -167,7 +177,7 @@ def main() -> None:
         comm = DP.open_comm(cp, ndev, lambda cp_: RcclComm(cp_, device=my_device))
     except DP.CommUnavailable as e:
         if cp.rank == 0:
-            print(json.dumps({"error": "RCCL is mandatory for --gpus > 1 and did not come up", "detail": str(e), "n_gpus": cp.world}))
+            emit({"error": "RCCL is mandatory for --gpus > 1 and did not come up", "detail": str(e), "n_gpus": cp.world})
         cp.shutdown()
         raise SystemExit(3)
 
@@ -412,7 +422,7 @@ def main() -> None:
     elif cp.rank == 0:
         result["cpu_baseline"] = None
     if cp.rank == 0:
-        print(json.dumps(result))
+        emit(result)
     cp.barrier()
     if comm is not None:
         comm.destroy()

@@ -90,8 +90,14 @@ __global__ __launch_bounds__(FL_THREADS, 2) void flash_fwd_kernel(const T* q, co
     const int kvh = id % hkv, rest = id / hkv;
     const int head = kvh * rep + rest % rep;
     const int rest2 = rest / rep;
-    const int split = rest2 % sp.nsplit;
-    const int qt = nqt - 1 - rest2 / sp.nsplit;
+    // heavy tiles first - and, when the launch is one round of two workgroups per CU (KV split), the second half of the ids in
+    // ASCENDING weight: a CU's two residents are then a heavy and a light run (ids i and i + grid / 2 sit on the same CU when
+    // the dispatcher deals one workgroup to every CU before the second)
+    int order = rest2;
+    const int nord = nqt * sp.nsplit;
+    if (sp.nsplit > 1 && order >= nord / 2) order = nord / 2 + (nord - 1 - order);
+    const int split = order % sp.nsplit;
+    const int qt = nqt - 1 - order / sp.nsplit;
     const int qw0 = qt * FL_BQ + wid * 32;          // first query row of this wave
     const int causal_off = kv_len - q_len;
     const T* qh = q + (size_t)head * sd.qh;

@@ -309,7 +309,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_bf16_kernel(const bf16* A,
 // count is constant.  64-byte rows: chunk c of row r at r*64 + ((c ^ ((r >> 2) & 2)) << 4).  ds_read_b128 is served in the
 // lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32), not in runs of 16 lanes: the first version's swizzle
 // (r >> 2) & 3 was conflict-free for runs of 16 and 2-way conflicted for the real groups (SQ_LDS_BANK_CONFLICT = half of
-// SQ_LDS_IDX_ACTIVE, profiles/r03_gemm256s_pmc.txt); (r >> 2) & 2 is conflict-free for them (exhaustive check).
+// SQ_LDS_IDX_ACTIVE on the round-2 kernel); (r >> 2) & 2 is conflict-free for them (exhaustive check; counter 0 in
+// profiles/r03_gemm256s_pmc.txt).
 // TN = n-fragments per wave column: 4 = 256-column tiles; 3 = 192-column tiles (EPI 0 only), for shapes whose 256-tiles leave a
 // half-empty last round: Llama's QKV (4096 x 6144) is 384 tiles = 1.5 rounds of the 256 CUs, 512 tiles of 256 x 192 are two
 // full rounds of three quarters the work.  The W stage then has 192 rows = 12 DMA instructions: waves 0-3 move two (rows 0-127),

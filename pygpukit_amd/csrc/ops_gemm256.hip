@@ -73,27 +73,29 @@ __device__ __forceinline__ void g2_tile_of(int id, int nwg, int ntm, int ntn, in
 // store 16 bytes of bf16, or (QOUT) 8 e4m3 codes with the row's scale for this 128-column block (absmax / 448 over the 16
 // lanes, quantize_fp8_rows' contract): exactly the fp8 x fp8 down projection's A operand.  Saves the [M][2 I] bf16 round
 // trip through HBM (Llama-3-8B shape, S = 4096: 235 MB written + read back = ~75 us of a 1.4 ms layer) and a launch.
-template <bool QOUT>
-__device__ __forceinline__ void g2_swiglu_epilogue(char* smem, const f32x4_g (&acc)[8][4], int tid, int m0, int tn, int M, int I,
+template <bool QOUT, int TN = 4>   // TN = n-fragments per wave column: 4 = 128 act columns per tile; 3 = 96 (bf16 output only)
+__device__ __forceinline__ void g2_swiglu_epilogue(char* smem, const f32x4_g (&acc)[8][TN], int tid, int m0, int tn, int M, int I,
                                                    void* outv, float* out_scales) {
+    static_assert(TN == 4 || !QOUT, "the e4m3 epilogue needs whole 128-column scale blocks");
+    constexpr int WN = TN * 16, ACT = 2 * WN, ROWB = 4 * WN * 2, CH = ACT / 8;       // act columns per tile, bytes per LDS row, 8-column chunks per row
     const int lane = tid & 63, wid = tid >> 6, wr = wid >> 2, wc = wid & 3, q = lane >> 4, l15 = lane & 15;
     __builtin_amdgcn_s_barrier();                    // every wave is past its last operand read (DMAs retired by the caller)
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = wr * 128 + i * 16 + q * 4 + r, colb = (wc * 64 + j * 16 + l15) * 2;
-                *reinterpret_cast<bf16*>(smem + row * 512 + (colb ^ (q << 5))) = from_f<bf16>(acc[i][j][r]);   // (row >> 2) & 3 == q
+                const int row = wr * 128 + i * 16 + q * 4 + r, colb = (wc * WN + j * 16 + l15) * 2;
+                *reinterpret_cast<bf16*>(smem + row * ROWB + (colb ^ (q << 5))) = from_f<bf16>(acc[i][j][r]);   // (row >> 2) & 3 == q; the XOR stays inside a 128-byte group
             }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int item = it * G2_THREADS + tid, row = item >> 4, c = item & 15, sw = ((row >> 2) & 3) << 5;
+    for (int it = 0; it < 256 * CH / G2_THREADS; ++it) {
+        const int item = it * G2_THREADS + tid, row = item / CH, c = item % CH, sw = ((row >> 2) & 3) << 5;
         Vec<bf16> g, u;
-        g.raw = *reinterpret_cast<const uint4*>(smem + row * 512 + ((c * 16) ^ sw));
-        u.raw = *reinterpret_cast<const uint4*>(smem + row * 512 + ((256 + c * 16) ^ sw));
+        g.raw = *reinterpret_cast<const uint4*>(smem + row * ROWB + ((c * 16) ^ sw));
+        u.raw = *reinterpret_cast<const uint4*>(smem + row * ROWB + ((ACT * 2 + c * 16) ^ sw));
         float gf[8], uf[8];
         g.to_float(gf);
         u.to_float(uf);
@@ -112,11 +114,11 @@ __device__ __forceinline__ void g2_swiglu_epilogue(char* smem, const f32x4_g (&a
             o.x = pack_fp8x4(gf[0] / sc, gf[1] / sc, gf[2] / sc, gf[3] / sc);
             o.y = pack_fp8x4(gf[4] / sc, gf[5] / sc, gf[6] / sc, gf[7] / sc);
             if (grow < (size_t)M) {
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(outv) + grow * I + tn * 128 + c * 8) = o;
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(outv) + grow * I + tn * ACT + c * 8) = o;
                 if (c == 0) out_scales[grow * (I >> 7) + tn] = sc;
             }
         } else {
-            if (grow < (size_t)M) g.store(reinterpret_cast<bf16*>(outv) + grow * I + tn * 128 + c * 8);
+            if (grow < (size_t)M) g.store(reinterpret_cast<bf16*>(outv) + grow * I + tn * ACT + c * 8);
         }
     }
 }
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_bf16_kernel(const bf16* A,
 template <int EPI, int TN = 4>   // EPI 0: bf16 C store (+bias); 1: fp32 C +=; 2: SwiGLU (W = fused gate / up rows, N = I act columns, C = bf16 act [M][I])
 __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A, const bf16* W, const bf16* bias, void* Cv,
                                                                     int M, int N, int K, int ntm, int ntn) {
-    static_assert(TN == 4 || (TN == 3 && EPI == 0), "192-column tiles: plain bf16 store only");
+    static_assert(TN == 4 || (TN == 3 && (EPI == 0 || EPI == 2)), "192-column tiles: bf16 store and SwiGLU only");
     extern __shared__ __attribute__((aligned(16))) char g2_smem[];   // 4 stages x (A 16 KiB | W 16 KiB)
     constexpr int HALF = 256 * 64, BN = TN * 64, WN = TN * 16;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -334,7 +336,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A
     const bf16* a_src1 = A + (size_t)min(m0 + drow + 16, M - 1) * K + dchunk * 8;
     // B-tile row r of an EPI-2 workgroup: gate row 128 tn + r for r < 128, up row N + 128 tn + (r - 128) after that (N = I)
     const int wtile_row = (TN == 4 || !late) ? drow : 128 + (wid - 4) * 16 + (lane >> 2);
-    const int wrow = (EPI == 2) ? (drow < 128 ? tn * 128 + drow : N + tn * 128 + drow - 128) : n0 + wtile_row;
+    constexpr int GATE = TN * 32;     // EPI 2: gate rows per B tile (128 / 96), the matching up rows follow
+    const int wrow = (EPI == 2) ? (wtile_row < GATE ? tn * GATE + wtile_row : N + tn * GATE + wtile_row - GATE) : n0 + wtile_row;
     const int wlast = (EPI == 2) ? 2 * N - 1 : N - 1;
     const bf16* w_src0 = W + (size_t)min(wrow, wlast) * K + dchunk * 8;
     const bf16* w_src1 = W + (size_t)min(wrow + 16, wlast) * K + dchunk * 8;
@@ -411,8 +414,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A
     if (!late) __builtin_amdgcn_s_barrier();                 // match the extra barrier of waves 4-7
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // retire the phantom DMAs before the LDS is given back
 
-    if constexpr (EPI == 2 && TN == 4) {
-        g2_swiglu_epilogue<false>(g2_smem, acc, tid, m0, tn, M, N, Cv, nullptr);
+    if constexpr (EPI == 2) {
+        g2_swiglu_epilogue<false, TN>(g2_smem, acc, tid, m0, tn, M, N, Cv, nullptr);
         return;
     }
     if constexpr (EPI == 1 && TN == 4) {
@@ -953,10 +956,17 @@ pgk_status gemm256_bf16_swiglu_nt(const bf16* A, const bf16* W, bf16* act, int M
     static bool attr_done = false;
     if (!attr_done) {
         PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_bf16_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_done = true;
     }
     const int ntm = ceil_div(M, G2_BM), ntn = I / 128;
-    gemm256s_bf16_kernel<2><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, nullptr, act, M, I, K, ntm, ntn);
+    // 96 act columns per tile (192-column B tiles) when that fills the rounds of the chip better: Qwen3-0.6B at S = 2048 is
+    // 8 x 24 = 192 tiles of 128 (three quarters of the CUs, one round) or 8 x 32 = 256 tiles of 96 (all of them)
+    if (I % 96 == 0 && 0.75 * ceil_div(ntm * (I / 96), 256) < (double)ceil_div(ntm * ntn, 256) - 0.01) {
+        gemm256s_bf16_kernel<2, 3><<<ntm * (I / 96), G2_THREADS, LDS, st>>>(A, W, nullptr, act, M, I, K, ntm, I / 96);
+    } else {
+        gemm256s_bf16_kernel<2><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, nullptr, act, M, I, K, ntm, ntn);
+    }
     PGK_CHECK_HIP(hipGetLastError());
     return PGK_OK;
 }

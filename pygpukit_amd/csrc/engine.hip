@@ -2311,12 +2311,9 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     PGK_REQUIRE(n >= 1 && start_pos >= 0 && start_pos + n <= c.max_seq_len, "pgk_engine_prefill: positions %d..%d outside cache of %d",
                 start_pos, start_pos + n, c.max_seq_len);
     hipStream_t st = resolve_stream(s);
-    // 129..256 tokens on the packed-weight path: two chunks of <= 128 through its kernels (5 launches per layer, the second
-    // chunk attending to the first through the cache) beat one pass through the generic GEMMs (9 launches per layer)
-    if (n > 128 && n <= 256 && e->packed_ok && all_logits == nullptr) {
-        if (pgk_status r = pgk_engine_prefill(eh, seq, h_tokens, 128, start_pos, nullptr, nullptr, s)) return r;
-        return pgk_engine_prefill(eh, seq, h_tokens + 128, n - 128, start_pos + 128, nullptr, h_last_logits, s);
-    }
+    // (prompts of 129..256 tokens used to run as two chunks of <= 128 through the packed-weight kernels; since the staged 128-tile
+    // GEMM and the epilogue fusions of round 3 the long-prompt path is faster at every such length: 144 tokens 1.94 vs 2.38 ms,
+    // 256 tokens 2.27 vs 2.62)
     const int H = c.hidden_size, I = c.intermediate_size, D = c.head_dim, QD = c.num_heads * D, NQKV = e->qkv_dim();
     // workspace: h32 [n,H] f32 | x [n,H] | qkv [n,NQKV] | attn [n,QD] | gu [n,2I] | act [n,I]  (bf16)
     // + split-K slabs of the N = hidden projections on the weight-streaming path (n <= 128)

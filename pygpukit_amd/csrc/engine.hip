@@ -1543,7 +1543,7 @@ struct Engine {
     void* sample_scratch = nullptr;   // top-k candidate keys (ops_sampling.hip), sized for max_batch rows
     size_t sample_scratch_cap = 0;
     int32_t* sampled = nullptr;    // [max_batch]
-    bool fused_attn = false;   // one or two sequences at short context: attn + o_proj in one kernel (bf16 W_o, shapes that tile)
+    bool fused_attn = false;   // one sequence at short context: attn + o_proj in one kernel (bf16 W_o, shapes that tile)
     bool attn_mfma = false;    // ... with Q.K^T and P.V on the matrix pipe from LDS-staged K/V (head_dim 128; PGK_ATTN_MFMA=0: the dot2 kernels); also the whole-context
                                // batch attention while its workgroups (96 KB of LDS: one per CU) fit one round - batch x Hkv <= CUs (beyond: attn_decode_kernel, batch 64 1.258 vs 1.316 ms)
     bool merged_oproj = false; // long contexts / fp8 W_o, one or two sequences: split-KV merge + o_proj in one kernel (PGK_MERGED_OPROJ=0: merge kernel + GEMV)
@@ -1672,7 +1672,7 @@ static hipError_t launch_attn_mfma(dim3 grid, hipStream_t st, const AttnArgs& a)
     return launch_k(attn_oproj_mfma_kernel<G, OPROJ>, grid, dim3(256), lds, st, a);
 }
 
-// `fused`: attention + o_proj partials in one kernel (one or two sequences at short context); `direct`: one workgroup per
+// `fused`: attention + o_proj partials in one kernel (one sequence at short context); `direct`: one workgroup per
 // (sequence, kv head) walks the whole (short) context and writes the normalised output - no merge launch; otherwise
 // split-KV slices, then `merged` (merge + o_proj partials in one launch) or the merge kernel.
 template <int D>
@@ -1777,7 +1777,7 @@ static pgk_status engine_sample(Engine* e, int b0, int M, hipStream_t st) {
 }
 
 // One decode step for sequences [b0, b0+M); `last` = this is the step's last chunk (bumps the step counter).
-// `short_ctx`: every sequence of the step has at most SHORT_CTX positions - one or two sequences then take the fused
+// `short_ctx`: every sequence of the step has at most SHORT_CTX positions - a single sequence then takes the fused
 // attention + o_proj kernel (4 L + 2 launches); otherwise split-KV slices + merge/o_proj (5 L + 2).  Both are correct at
 // any context: the choice follows the context of the step, not the capacity of the cache (pgk_engine_replay).
 template <class WT, class XT, int M>
@@ -1786,13 +1786,15 @@ static pgk_status decode_chunk(Engine* e, int b0, bool last, hipStream_t st, int
     const int H = c.hidden_size, I = c.intermediate_size, D = c.head_dim, QD = c.num_heads * D, NQKV = e->qkv_dim();
     float* h = e->h + (size_t)b0 * H;
     float* h2 = e->h2 + (size_t)b0 * H;
-    // fused attention+o_proj recomputes a KV head's attention in every row-slice workgroup: right for one or
-    // two sequences at short context, wasteful for a batch - batches take the split-KV path.
-    const bool fused = e->fused_attn && short_ctx && M <= 2;
+    // fused attention+o_proj recomputes a KV head's attention in every row-slice workgroup: right for one
+    // sequence at short context, wasteful for a batch.
+    // (two sequences ran the fused kernel too until round 3: its 96-KB workgroups are one per CU, so 2 x 256 of them took two
+    // rounds - 9.4 us per layer against 3.7 + 2.4 for whole-context attention + an o_proj GEMV: 0.80 -> 0.66 ms per step)
+    const bool fused = e->fused_attn && short_ctx && M == 1;
+    const bool direct = !fused && short_ctx && M >= 2;
     // long contexts (or fp8 W_o): split-KV slices, then merge + o_proj partials in one launch; the gate/up prologue adds them
-    const bool merged = !fused && M <= 2 && e->merged_oproj;
+    const bool merged = !fused && !direct && M <= 2 && e->merged_oproj;
     const bool partials = fused || merged;
-    const bool direct = !fused && short_ctx && M >= 3;
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& L = e->layers[l];
         FusedArgs a{};

@@ -36,10 +36,11 @@ namespace pgk {
 constexpr int SHORT_CTX = 512;   // contexts up to here take the whole-context attention kernels (fused o_proj / direct batch attention)
 
 pgk_status engine_gemm_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, void* C, bool accum_f32, int M,
-                          int N, int K, hipStream_t st);
+                          int N, int K, hipStream_t st, bool packed = false);      // packed: W = the fragment-major bf16 copy
+bool engine_gemm_packed_ok(int M, int N, int K);
 int wsgemm_pick_splits(int N, int K, bool allow_split);
 int engine_gemm_pick_splits(int M, int N, int K);
-pgk_status engine_gemm_nt_slabs(const bf16* A, const void* W, float* slabs, int splits, int M, int N, int K, hipStream_t st);
+pgk_status engine_gemm_nt_slabs(const bf16* A, const void* W, float* slabs, int splits, int M, int N, int K, hipStream_t st, bool packed = false);
 pgk_status gemm_fp8_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, void* c, bool accum_f32, int M,
                        int N, int K, hipStream_t st);
 pgk_status quantize_fp8_rows_bf16(const bf16* x, uint8_t* out, float* scale, int M, int K, hipStream_t st);
@@ -47,9 +48,9 @@ bool sdpa_flash_enabled();                                     // ops_attention.
 pgk_status flash_prefill_q8(const void* q, const void* k, const void* v, uint8_t* q8, float* q8s, int hq, int hkv, int q_len, int kv_len,
                             float scale, long long qh, long long qs, long long kh, long long ks, hipStream_t st);   // ops_flash.hip
 bool engine_gemm_qkv_heads_ok(int M, int N, int K);            // ops_gemm.hip: QKV projection with per-head norm + RoPE + cache write as its epilogue
-pgk_status engine_gemm_qkv_heads_nt(const bf16* A, const bf16* W, bf16* qkv, int M, int N, int K, const QkvHeadArgs& hd, hipStream_t st);
+pgk_status engine_gemm_qkv_heads_nt(const bf16* A, const bf16* W, bf16* qkv, int M, int N, int K, const QkvHeadArgs& hd, hipStream_t st, bool packed = false);
 bool engine_gemm_swiglu_ok(int M, int I, int K, bool fp8);     // ops_gemm.hip: gate / up projection with the SwiGLU epilogue
-pgk_status engine_gemm_swiglu_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, bf16* act, int M, int I, int K, hipStream_t st);
+pgk_status engine_gemm_swiglu_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, bf16* act, int M, int I, int K, hipStream_t st, bool packed = false);
 bool gemm_fp8_qkv_heads_ok(int M, int N, int K);               // ops_fp8_gemm.hip: the same epilogue on the fp8 x fp8 256-tile kernel
 pgk_status gemm_fp8_qkv_heads_nt(const uint8_t* a, const float* sa, const uint8_t* w, const bf16* sw, bf16* qkv, int M, int N, int K,
                                  const QkvHeadArgs& hd, hipStream_t st);
@@ -1564,7 +1565,8 @@ struct Engine {
     // fragment-major copies of the layer weights for prompts of <= 128 tokens (ops_pkgemm.hip); PGK_PACKED_PREFILL=0: none
     struct PackedLayer { bf16 *qkv = nullptr, *o = nullptr, *gate_up = nullptr, *down = nullptr; };
     std::vector<PackedLayer> packed;
-    bool packed_ok = false;
+    bool packed_ok = false;     // the skinny-GEMM kernels of ops_pkgemm.hip can use the copy (their shape limits)
+    bool packed_have = false;   // the copy exists (w8a16 engines: also for shapes beyond those kernels - the long-prompt GEMMs read it)
     size_t packed_bytes = 0;
     bool packed_resid = false;      // o_proj / down_proj without K split, carrying the next RMSNorm (pkgemm_resid_nt); PGK_PACKED_RESID=0: split-K slabs + norm launches
     float* pk_ss = nullptr;         // its sum-of-squares table [128][PK_SS_LD]
@@ -2219,7 +2221,10 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
         const bool shapes = pkgemm_shape_ok(NQ, H, false) && pkgemm_shape_ok(H, QDp, true) && pkgemm_shape_ok(2 * I, H, false) && pkgemm_shape_ok(H, I, true) && I % 64 == 0;
         // bf16 layers, or fp8 codes + block scales (w8a16): the copy is bf16 either way (ops_pkgemm.hip)
         const bool f8w = c.weight_format == 1;
-        if (r == PGK_OK && (c.weight_format == 0 || f8w) && shapes && fits && !(ep && atoi(ep) == 0)) {
+        // w8a16 engines keep the copy also where the skinny kernels cannot use it (Llama-3-8B: K = 4096 / 14336 is beyond them):
+        // their long-prompt GEMMs read it (packed_have), instead of dequantising every weight again in front of every call
+        const bool long_only = f8w && !shapes && NQ % 16 == 0 && H % 64 == 0 && QDp % 64 == 0 && I % 64 == 0;
+        if (r == PGK_OK && (c.weight_format == 0 || f8w) && (shapes || long_only) && fits && !(ep && atoi(ep) == 0)) {
             e->packed.resize(c.num_layers);
             hipStream_t st = resolve_stream(nullptr);
             for (int l = 0; l < c.num_layers && r == PGK_OK; ++l) {
@@ -2235,7 +2240,8 @@ pgk_status pgk_engine_create(const pgk_model_config_t* cfg, const void* embed, c
                 if (r == PGK_OK) r = f8w ? pack_weights_fp8(L.w_down, L.s_down, P.down, H, I, st) : pack_weights_bf16(L.w_down, P.down, H, I, st);
             }
             if (r == PGK_OK && hipStreamSynchronize(st) != hipSuccess) r = set_error(PGK_ERR_HIP, "pgk_engine_create: packing the prefill weights failed");
-            e->packed_ok = r == PGK_OK;
+            e->packed_have = r == PGK_OK;
+            e->packed_ok = e->packed_have && shapes;
             if (e->packed_ok && pkgemm_resid_ok(H, QDp) && pkgemm_resid_ok(H, I)) {
                 A((void**)&e->pk_ss, (size_t)128 * PK_SS_LD * 4, &e->ws_bytes);
                 e->packed_resid = r == PGK_OK;
@@ -2329,7 +2335,13 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     const bool pk_heads = pk && D == 128;       // QKV epilogue: per-head norm + RoPE + cache write inside the projection
     // long prompts, bf16 weights: the N = hidden projections as split-K slabs when their 128-tiles do not cover the chip
     // (QKV / gate_up were tried too - their consumers can sum slabs - and measured slightly slower: 3.06 vs 2.99 ms at S = 512)
-    const bool gsplit = !ws && c.weight_format == 0;
+    // w8a16 engines, long prompts: the staged bf16 GEMMs read the DEQUANTISED fragment-major copy the engine already holds
+    // (pack_weights_fp8: bf16(code x scale), the value the reference's w8a16 GEMM multiplies) - same kernels, epilogues and
+    // times as a bf16 engine (S = 512: 4.23 -> 2.44 ms) instead of the in-staging-dequant 128-tile kernel / a per-call
+    // dequantisation pass in front of the 256-tile kernel
+    const bool pkd = !ws && c.weight_format == 1 && e->packed_have && engine_gemm_packed_ok(n, NQKV, H) && engine_gemm_packed_ok(n, H, QD) &&
+                     engine_gemm_packed_ok(n, 2 * I, H) && engine_gemm_packed_ok(n, H, I);
+    const bool gsplit = !ws && (c.weight_format == 0 || pkd);
     const int g_so = gsplit ? engine_gemm_pick_splits(n, H, QD) : 1, g_sd = gsplit ? engine_gemm_pick_splits(n, H, I) : 1;
     const bool use_slabs = ws || g_so > 1 || g_sd > 1;
     size_t slab_elems = (size_t)(s_o > s_d ? s_o : s_d) * n * H;
@@ -2378,19 +2390,21 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
     const bool fuse_q = fp8act && H % 128 == 0 && I % 128 == 0 && H <= 4096 && fuse_epi;
     // SwiGLU in the gate / up GEMM's epilogue (256-tile kernels; fp8 x fp8: with the quantisation of its result)
     const bool fuse_sw8 = fuse_q && gemm_fp8_swiglu_ok(n, I, H);
-    const bool fuse_sw16 = !fp8act && !ws && fuse_epi && engine_gemm_swiglu_ok(n, I, H, fp8);
+    const bool fuse_sw16 = !fp8act && !ws && fuse_epi && engine_gemm_swiglu_ok(n, I, H, fp8 && !pkd);
     // per-head norm + RoPE + cache write in the QKV GEMM's epilogue (bf16 weights, head_dim 128, 128-tile kernel: tile column = head)
     const bool fuse_heads8 = fuse_q && D == 128 && gemm_fp8_qkv_heads_ok(n, NQKV, H);      // fp8 x fp8: x's codes are already in q8
-    const bool fuse_heads = fuse_heads8 || (!ws && !pk && fuse_epi && c.weight_format == 0 && D == 128 && engine_gemm_qkv_heads_ok(n, NQKV, H));
-    auto proj_accum = [&](const bf16* x_in, const void* w, const void* sc, int N_, int K_, int splits) -> pgk_status {
+    const bool fuse_heads = fuse_heads8 || (!ws && !pk && fuse_epi && (c.weight_format == 0 || pkd) && D == 128 && engine_gemm_qkv_heads_ok(n, NQKV, H));
+    auto proj_accum = [&](const bf16* x_in, const void* w, const void* sc, int N_, int K_, int splits, const bf16* wp = nullptr) -> pgk_status {
         if (fp8act) {
             if (x_in)
                 if (pgk_status r = quantize_fp8_rows_bf16(x_in, q8, q8s, n, K_, st)) return r;
             return gemm_fp8_nt(q8, q8s, (const uint8_t*)w, (const bf16*)sc, h32, true, n, N_, K_, st);
         }
         if (!ws) {
+            const bool usep = pkd && wp != nullptr;
             const int gs = gsplit ? engine_gemm_pick_splits(n, N_, K_) : 1;
-            if (gs > 1) { pending = gs; return engine_gemm_nt_slabs(x_in, w, slabs, gs, n, N_, K_, st); }
+            if (gs > 1) { pending = gs; return engine_gemm_nt_slabs(x_in, usep ? (const void*)wp : w, slabs, gs, n, N_, K_, st, usep); }
+            if (usep) return engine_gemm_nt(x_in, wp, nullptr, false, h32, true, n, N_, K_, st, true);
             return engine_gemm_nt(x_in, w, (const bf16*)sc, fp8, h32, true, n, N_, K_, st);
         }
         if (splits == 1) return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, h32, nullptr, 2, 1, n, N_, K_, st);
@@ -2398,12 +2412,13 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
         return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, slabs, nullptr, 1, splits, n, N_, K_, st);
     };
     // with splits > 1 the result is left as fp32 split-K slabs for the consumer kernel to sum
-    auto proj_store = [&](const bf16* x_in, const void* w, const void* sc, bf16* out_, int N_, int K_, int splits) -> pgk_status {
+    auto proj_store = [&](const bf16* x_in, const void* w, const void* sc, bf16* out_, int N_, int K_, int splits, const bf16* wp = nullptr) -> pgk_status {
         if (fp8act) {
             if (x_in)
                 if (pgk_status r = quantize_fp8_rows_bf16(x_in, q8, q8s, n, K_, st)) return r;
             return gemm_fp8_nt(q8, q8s, (const uint8_t*)w, (const bf16*)sc, out_, false, n, N_, K_, st);
         }
+        if (!ws && pkd && wp != nullptr) return engine_gemm_nt(x_in, wp, nullptr, false, out_, false, n, N_, K_, st, true);
         if (!ws) return engine_gemm_nt(x_in, w, (const bf16*)sc, fp8, out_, false, n, N_, K_, st);
         if (splits > 1) return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, slabs, nullptr, 1, splits, n, N_, K_, st);
         return wsgemm_nt(x_in, K_, w, (const bf16*)sc, fp8, out_, nullptr, 0, 1, n, N_, K_, st);
@@ -2450,9 +2465,9 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
             hd.hq = c.num_heads; hd.hkv = c.num_kv_heads; hd.max_seq = c.max_seq_len; hd.start_pos = start_pos;
             if (fuse_heads8) {
                 if (pgk_status r = gemm_fp8_qkv_heads_nt(q8, q8s, (const uint8_t*)L.w_qkv, (const bf16*)L.s_qkv, qkv, n, NQKV, H, hd, st)) return r;
-            } else if (pgk_status r = engine_gemm_qkv_heads_nt(x, (const bf16*)L.w_qkv, qkv, n, NQKV, H, hd, st)) return r;
+            } else if (pgk_status r = engine_gemm_qkv_heads_nt(x, pkd ? e->packed[l].qkv : (const bf16*)L.w_qkv, qkv, n, NQKV, H, hd, st, pkd)) return r;
         } else {
-            if (pgk_status r = proj_store(fuse_q ? nullptr : x, L.w_qkv, L.s_qkv, qkv, NQKV, H, s_qkv)) return r;
+            if (pgk_status r = proj_store(fuse_q ? nullptr : x, L.w_qkv, L.s_qkv, qkv, NQKV, H, s_qkv, pkd ? e->packed[l].qkv : nullptr)) return r;
         }
         if (!pk_heads && !fuse_heads) {
             const int s_qkv = pk ? 1 : s_qkv_ws;
@@ -2496,7 +2511,7 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
             continue;
         }
         if (pk) { if (pgk_status r = pk_accum(attn, e->packed[l].o, QD, pk_so)) return r; }
-        else if (pgk_status r = proj_accum(attn_q8 ? nullptr : attn, L.w_o, L.s_o, H, QD, s_o)) return r;
+        else if (pgk_status r = proj_accum(attn_q8 ? nullptr : attn, L.w_o, L.s_o, H, QD, s_o, pkd ? e->packed[l].o : nullptr)) return r;
         if (pgk_status r = norm((const bf16*)L.mlp_norm, fuse_q)) return r;
         if (pk) {
             // SwiGLU inside the gate_up projection: the gate tile and its up tile live in the same wave
@@ -2511,15 +2526,15 @@ pgk_status pgk_engine_prefill(pgk_engine eh, int seq, const int32_t* h_tokens, i
             continue;
         }
         if (fuse_sw16) {
-            if (pgk_status r = engine_gemm_swiglu_nt(x, L.w_gate_up, (const bf16*)L.s_gate_up, fp8, act, n, I, H, st)) return r;
-            if (pgk_status r = proj_accum(act, L.w_down, L.s_down, H, I, s_d)) return r;
+            if (pgk_status r = engine_gemm_swiglu_nt(x, pkd ? (const void*)e->packed[l].gate_up : L.w_gate_up, (const bf16*)L.s_gate_up, fp8 && !pkd, act, n, I, H, st, pkd)) return r;
+            if (pgk_status r = proj_accum(act, L.w_down, L.s_down, H, I, s_d, pkd ? e->packed[l].down : nullptr)) return r;
             continue;
         }
-        if (pgk_status r = proj_store(fuse_q ? nullptr : x, L.w_gate_up, L.s_gate_up, gu, 2 * I, H, s_gu)) return r;
+        if (pgk_status r = proj_store(fuse_q ? nullptr : x, L.w_gate_up, L.s_gate_up, gu, 2 * I, H, s_gu, pkd ? e->packed[l].gate_up : nullptr)) return r;
         swiglu_rows_kernel<<<ceil_div((long long)n * I / 8, 256) > 2048 ? 2048 : ceil_div((long long)n * I / 8, 256), 256, 0, st>>>(
             gu, act, n, I, slabs, s_gu > 1 ? s_gu : 0, fuse_q ? q8 : nullptr, fuse_q ? q8s : nullptr);
         PGK_LAUNCH_CHECK();
-        if (pgk_status r = proj_accum(fuse_q ? nullptr : act, L.w_down, L.s_down, H, I, s_d)) return r;
+        if (pgk_status r = proj_accum(fuse_q ? nullptr : act, L.w_down, L.s_down, H, I, s_d, pkd ? e->packed[l].down : nullptr)) return r;
     }
     if (pgk_status r = norm(e->final_norm)) return r;
     if (all_logits) {

@@ -20,12 +20,14 @@ namespace pgk {
 template <class T> pgk_status launch_gemv(const T*, const T*, const T*, T*, int, int, int, hipStream_t);
 pgk_status wsgemm_nt(const bf16* a, int lda, const void* w, const bf16* wscale, bool fp8, void* c, const bf16* bias, int mode,
                      int splits, int M, int N, int K, hipStream_t st);
+// (packed: W is the fragment-major bf16 copy of ops_pkgemm.hip instead of the row-major weight - the staged kernels' DMA
+// instruction moves 16 rows x 32 k, which is one block of that layout)
 pgk_status gemm256_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, bool accum_f32, int M, int N, int K,
-                           hipStream_t st);
-pgk_status gemm256_bf16_swiglu_nt(const bf16* A, const bf16* W, bf16* act, int M, int I, int K, hipStream_t st);
+                           hipStream_t st, bool packed = false);
+pgk_status gemm256_bf16_swiglu_nt(const bf16* A, const bf16* W, bf16* act, int M, int I, int K, hipStream_t st, bool packed = false);
 bool gemm128s_ok(int M, int N, int K);    // ops_gemm256.hip: 128 x 128 tiles on the staged LDS-DMA pipeline (bf16, M > 128, K % 64 == 0, N % 8 == 0)
 pgk_status gemm128s_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, int mode, int splits, int M, int N, int K, hipStream_t st,
-                            const QkvHeadArgs* heads = nullptr);
+                            const QkvHeadArgs* heads = nullptr, bool packed = false);
 // the 256 x 256 structure needs enough tiles to fill the chip and whole 128-byte K rows
 // PGK_GEMM256 = 0 / 1 forces the choice (read per call: tests flip it to drive small shapes through both kernels); shared
 // with the fp8 x fp8 GEMM (ops_fp8_gemm.hip)
@@ -396,16 +398,25 @@ int engine_gemm_pick_splits(int M, int N, int K) {
     while (s > 1 && (K / s < 512 || (gemm128s_ok(M, N, K) && K % (64 * s) != 0))) --s;
     return s < 1 ? 1 : s;
 }
-pgk_status engine_gemm_nt_slabs(const bf16* A, const void* W, float* slabs, int splits, int M, int N, int K, hipStream_t st) {
+pgk_status engine_gemm_nt_slabs(const bf16* A, const void* W, float* slabs, int splits, int M, int N, int K, hipStream_t st, bool packed) {
     PGK_REQUIRE(splits >= 2 && K % 8 == 0, "engine_gemm_nt_slabs: splits=%d K=%d", splits, K);
-    if (gemm128s_ok(M, N, K) && K % (64 * splits) == 0) return gemm128s_bf16_nt(A, (const bf16*)W, nullptr, slabs, 2, splits, M, N, K, st);
+    if (gemm128s_ok(M, N, K) && K % (64 * splits) == 0) return gemm128s_bf16_nt(A, (const bf16*)W, nullptr, slabs, 2, splits, M, N, K, st, nullptr, packed);
+    PGK_REQUIRE(!packed, "engine_gemm_nt_slabs: M=%d N=%d K=%d splits=%d has no kernel that reads the fragment-major copy", M, N, K, splits);
     return launch_mfma<bf16, 128, 128, B_NT, 2>(A, W, nullptr, nullptr, slabs, M, N, K, st, splits);
 }
 
 // internal (engine prefill): bf16 A against a bf16 or fp8 (+128x128 bf16 block scales) weight W[N,K];
 // either a bf16 result or an fp32 "+=" into the residual stream.
+// the shapes whose kernels can read the fragment-major bf16 copy (engine_gemm_nt and friends with packed = true)
+bool engine_gemm_packed_ok(int M, int N, int K) { return N % 16 == 0 && K % 64 == 0 && (use_gemm256(M, N, K) || gemm128s_ok(M, N, K)); }
+
 pgk_status engine_gemm_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, void* C, bool accum_f32, int M,
-                          int N, int K, hipStream_t st) {
+                          int N, int K, hipStream_t st, bool packed) {
+    if (packed) {
+        PGK_REQUIRE(!fp8 && engine_gemm_packed_ok(M, N, K), "engine_gemm_nt: M=%d N=%d K=%d has no kernel that reads the fragment-major copy", M, N, K);
+        if (use_gemm256(M, N, K)) return gemm256_bf16_nt(A, (const bf16*)W, nullptr, C, accum_f32, M, N, K, st, true);
+        return gemm128s_bf16_nt(A, (const bf16*)W, nullptr, C, accum_f32 ? 1 : 0, 1, M, N, K, st, nullptr, true);
+    }
     if (fp8 && use_gemm256(M, N, K) && K % 128 == 0 && N % 128 == 0) {
         // large w8a16 products: dequantise the weight once into a bf16 scratch (a ~10 % extra pass over memory) and run
         // the LDS-DMA bf16 kernel, instead of dequantising in the staging path of the 128-tile kernel (0.58 vs ~1 PFLOP/s)
@@ -432,9 +443,9 @@ pgk_status engine_gemm_nt(const bf16* A, const void* W, const bf16* wscale, bool
 // epilogue (QkvHeadArgs) - on the 128-tile kernel, whose tile columns are whole heads; where engine_gemm_nt would pick the
 // 256-tile kernel the separate pass stays
 bool engine_gemm_qkv_heads_ok(int M, int N, int K) { return N % 128 == 0 && gemm128s_ok(M, N, K) && !use_gemm256(M, N, K); }
-pgk_status engine_gemm_qkv_heads_nt(const bf16* A, const bf16* W, bf16* qkv, int M, int N, int K, const QkvHeadArgs& hd, hipStream_t st) {
+pgk_status engine_gemm_qkv_heads_nt(const bf16* A, const bf16* W, bf16* qkv, int M, int N, int K, const QkvHeadArgs& hd, hipStream_t st, bool packed) {
     PGK_REQUIRE(engine_gemm_qkv_heads_ok(M, N, K), "engine_gemm_qkv_heads: M=%d N=%d K=%d outside the fused kernel's shapes", M, N, K);
-    return gemm128s_bf16_nt(A, W, nullptr, qkv, 3, 1, M, N, K, st, &hd);
+    return gemm128s_bf16_nt(A, W, nullptr, qkv, 3, 1, M, N, K, st, &hd, packed);
 }
 
 // internal (engine prefill): act[M][I] = bf16(silu(A . Wg^T) * (A . Wu^T)) on the fused [2 I, K] gate / up weight (bf16, or fp8 with
@@ -445,10 +456,10 @@ bool engine_gemm_swiglu_ok(int M, int I, int K, bool fp8) {
     if (I % 128 == 0 && use_gemm256(M, 2 * I, K) && (!fp8 || K % 128 == 0)) return true;
     return !fp8 && I % 64 == 0 && gemm128s_ok(M, I, K);
 }
-pgk_status engine_gemm_swiglu_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, bf16* act, int M, int I, int K, hipStream_t st) {
-    PGK_REQUIRE(engine_gemm_swiglu_ok(M, I, K, fp8), "engine_gemm_swiglu: M=%d I=%d K=%d outside the fused kernel's shapes", M, I, K);
-    if (!(I % 128 == 0 && use_gemm256(M, 2 * I, K))) return gemm128s_bf16_nt(A, (const bf16*)W, nullptr, act, 4, 1, M, I, K, st);
-    if (!fp8) return gemm256_bf16_swiglu_nt(A, (const bf16*)W, act, M, I, K, st);
+pgk_status engine_gemm_swiglu_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, bf16* act, int M, int I, int K, hipStream_t st, bool packed) {
+    PGK_REQUIRE(engine_gemm_swiglu_ok(M, I, K, fp8) && !(packed && fp8), "engine_gemm_swiglu: M=%d I=%d K=%d outside the fused kernel's shapes", M, I, K);
+    if (!(I % 128 == 0 && use_gemm256(M, 2 * I, K))) return gemm128s_bf16_nt(A, (const bf16*)W, nullptr, act, 4, 1, M, I, K, st, nullptr, packed);
+    if (!fp8) return gemm256_bf16_swiglu_nt(A, (const bf16*)W, act, M, I, K, st, packed);
     void* wb = nullptr;
     if (pgk_status r = pgk_malloc(&wb, (size_t)2 * I * K * sizeof(bf16))) return r;
     const size_t chunks = (size_t)2 * I * K / 16;
@@ -518,7 +529,7 @@ pgk_status pgk_w8a16_gemm_nk(const void* a, const uint8_t* w_nk, const void* sca
     PGK_REQUIRE(aligned16(a) && aligned16(w_nk), "pgk_w8a16_gemm_nk: operands must be 16-byte aligned");
     if (!m) return PGK_OK;
     if (m <= 128) return wsgemm_nt((const bf16*)a, k, w_nk, (const bf16*)scale, true, c, nullptr, 0, 1, m, n, k, resolve_stream(s));
-    return engine_gemm_nt((const bf16*)a, w_nk, (const bf16*)scale, true, c, false, m, n, k, resolve_stream(s));
+    return engine_gemm_nt((const bf16*)a, w_nk, (const bf16*)scale, true, c, false, m, n, k, resolve_stream(s), false);
 }
 
 pgk_status pgk_w8a16_gemm_kn(const void* a, const uint8_t* b_kn, const void* scale, void* c, int m, int n, int k,

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_bf16_kernel(const bf16* A,
 // waves 4-7 one (rows 128-191), so the "two younger stages in flight" count is vmcnt(8) for the former, vmcnt(6) for the latter.
 template <int EPI, int TN = 4>   // EPI 0: bf16 C store (+bias); 1: fp32 C +=; 2: SwiGLU (W = fused gate / up rows, N = I act columns, C = bf16 act [M][I])
 __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A, const bf16* W, const bf16* bias, void* Cv,
-                                                                    int M, int N, int K, int ntm, int ntn) {
+                                                                    int M, int N, int K, int ntm, int ntn, int packed) {
     static_assert(TN == 4 || (TN == 3 && (EPI == 0 || EPI == 2)), "192-column tiles: bf16 store and SwiGLU only");
     extern __shared__ __attribute__((aligned(16))) char g2_smem[];   // 4 stages x (A 16 KiB | W 16 KiB)
     constexpr int HALF = 256 * 64, BN = TN * 64, WN = TN * 16;
@@ -339,23 +339,35 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256s_bf16_kernel(const bf16* A
     constexpr int GATE = TN * 32;     // EPI 2: gate rows per B tile (128 / 96), the matching up rows follow
     const int wrow = (EPI == 2) ? (wtile_row < GATE ? tn * GATE + wtile_row : N + tn * GATE + wtile_row - GATE) : n0 + wtile_row;
     const int wlast = (EPI == 2) ? 2 * N - 1 : N - 1;
-    const bf16* w_src0 = W + (size_t)min(wrow, wlast) * K + dchunk * 8;
-    const bf16* w_src1 = W + (size_t)min(wrow + 16, wlast) * K + dchunk * 8;
+    // W row-major [rows][K], or (packed) the fragment-major copy of ops_pkgemm.hip: block (16-row tile nt, k-step ks) = 1 KiB at
+    // ((nt K/32 + ks) 64 + chunk 16 + row) 8 elements.  One DMA instruction moves 16 rows x 32 k = exactly one such block; only
+    // the per-lane source offset inside it differs (this lane's logical chunk and row), and a stage advances 512 elements.
+    const bf16 *w_src0, *w_src1;
+    const int wk = packed ? 512 : 32;
+    if (packed) {
+        const int r_in = lane >> 2, nt_last = (wlast >> 4);
+        w_src0 = W + ((size_t)min((wrow - r_in) >> 4, nt_last) * (K >> 5) * 64 + dchunk * 16 + r_in) * 8;
+        w_src1 = W + ((size_t)min((wrow - r_in + 16) >> 4, nt_last) * (K >> 5) * 64 + dchunk * 16 + r_in) * 8;
+    } else {
+        w_src0 = W + (size_t)min(wrow, wlast) * K + dchunk * 8;
+        w_src1 = W + (size_t)min(wrow + 16, wlast) * K + dchunk * 8;
+    }
     const uint32_t lds0 = g2_lds_addr(g2_smem);
     const int nh = K / 32;
     auto stage = [&](int h, int buf) {
-        const int k = min(h, nh - 1) * 32;
+        const int hc = min(h, nh - 1), k = hc * 32;
+        const size_t kw = (size_t)hc * wk;
         const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds0 + buf * 2 * HALF + wid * 2048);
         g2_dma16(a_src0 + k, a_dst);
         g2_dma16(a_src1 + k, a_dst + 1024);
         if constexpr (TN == 4) {
-            g2_dma16(w_src0 + k, a_dst + HALF);
-            g2_dma16(w_src1 + k, a_dst + HALF + 1024);
+            g2_dma16(w_src0 + kw, a_dst + HALF);
+            g2_dma16(w_src1 + kw, a_dst + HALF + 1024);
         } else if (!late) {
-            g2_dma16(w_src0 + k, a_dst + HALF);
-            g2_dma16(w_src1 + k, a_dst + HALF + 1024);
+            g2_dma16(w_src0 + kw, a_dst + HALF);
+            g2_dma16(w_src1 + kw, a_dst + HALF + 1024);
         } else {
-            g2_dma16(w_src0 + k, __builtin_amdgcn_readfirstlane(lds0 + buf * 2 * HALF + HALF + 128 * 64 + (wid - 4) * 1024));
+            g2_dma16(w_src0 + kw, __builtin_amdgcn_readfirstlane(lds0 + buf * 2 * HALF + HALF + 128 * 64 + (wid - 4) * 1024));
         }
     };
     // "this wave's share of the oldest of three stages in flight has landed"
@@ -457,7 +469,7 @@ constexpr int G1_THREADS = 256, G1_HALF = 128 * 64;
 template <int EPI>   // 0: bf16 C store (+bias); 1: fp32 C +=; 2: fp32 split-K slab; 3: QKV heads (QkvHeadArgs: tile column = head slot);
                      // 4: SwiGLU (W = fused gate / up rows, N = I act columns, C = bf16 act [M][I]; tile tn = act columns [64 tn, +64))
 __global__ __launch_bounds__(G1_THREADS, 2) void gemm128s_bf16_kernel(const bf16* A, const bf16* W, const bf16* bias, void* Cv,
-                                                                       int M, int N, int K, int ntm, int ntn, int kps, QkvHeadArgs hd) {
+                                                                       int M, int N, int K, int ntm, int ntn, int kps, QkvHeadArgs hd, int packed) {
     extern __shared__ __attribute__((aligned(16))) char g2_smem[];   // 4 stages x (A 8 KiB | W 8 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1, q = lane >> 4, l15 = lane & 15;
@@ -473,17 +485,27 @@ __global__ __launch_bounds__(G1_THREADS, 2) void gemm128s_bf16_kernel(const bf16
     // EPI 4: B-tile rows 0-63 = gate rows 64 tn .., rows 64-127 = the matching up rows N + 64 tn .. (N = I); a wave's 32 rows stay in one half
     const int wrow = (EPI == 4) ? (drow < 64 ? tn * 64 + drow : N + tn * 64 + drow - 64) : n0 + drow;
     const int wlast = (EPI == 4) ? 2 * N - 1 : N - 1;
-    const bf16* w_src0 = W + (size_t)min(wrow, wlast) * K + kbeg + dchunk * 8;
-    const bf16* w_src1 = W + (size_t)min(wrow + 16, wlast) * K + kbeg + dchunk * 8;
+    // W row-major, or (packed) the fragment-major copy: see gemm256s_bf16_kernel
+    const bf16 *w_src0, *w_src1;
+    const int wk = packed ? 512 : 32;
+    if (packed) {
+        const int r_in = lane >> 2, nt_last = (wlast >> 4);
+        w_src0 = W + (((size_t)min((wrow - r_in) >> 4, nt_last) * (K >> 5) + (kbeg >> 5)) * 64 + dchunk * 16 + r_in) * 8;
+        w_src1 = W + (((size_t)min((wrow - r_in + 16) >> 4, nt_last) * (K >> 5) + (kbeg >> 5)) * 64 + dchunk * 16 + r_in) * 8;
+    } else {
+        w_src0 = W + (size_t)min(wrow, wlast) * K + kbeg + dchunk * 8;
+        w_src1 = W + (size_t)min(wrow + 16, wlast) * K + kbeg + dchunk * 8;
+    }
     const uint32_t lds0 = g2_lds_addr(g2_smem);
     const int nh = (kend - kbeg) / 32;
     auto stage = [&](int h, int buf) {
-        const int k = min(h, nh - 1) * 32;                   // past the end: re-read the last stage (never consumed), the count stays constant
+        const int hc = min(h, nh - 1), k = hc * 32;          // past the end: re-read the last stage (never consumed), the count stays constant
+        const size_t kw = (size_t)hc * wk;
         const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds0 + buf * 2 * G1_HALF + wid * 2048);
         g2_dma16(a_src0 + k, a_dst);
         g2_dma16(a_src1 + k, a_dst + 1024);
-        g2_dma16(w_src0 + k, a_dst + G1_HALF);
-        g2_dma16(w_src1 + k, a_dst + G1_HALF + 1024);
+        g2_dma16(w_src0 + kw, a_dst + G1_HALF);
+        g2_dma16(w_src1 + kw, a_dst + G1_HALF + 1024);
     };
 
     f32x4_g acc[4][4];
@@ -909,8 +931,9 @@ pgk_status gemm256_fp8_swiglu_nt(const uint8_t* a, const float* sa, const uint8_
 
 // bf16 NT on the 256^2 structure; caller guarantees K % 64 == 0 and 16-byte aligned rows
 pgk_status gemm256_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, bool accum_f32, int M, int N, int K,
-                           hipStream_t st) {
+                           hipStream_t st, bool packed) {
     PGK_REQUIRE(K % 64 == 0 && K >= 64, "gemm256: K=%d must be a multiple of 64", K);
+    PGK_REQUIRE(!packed || N % 16 == 0, "gemm256: the fragment-major weight copy has whole 16-row tiles (N=%d)", N);
     constexpr size_t LDS = 4 * (size_t)G2_TILE;
     static bool attr_done = false;
     if (!attr_done) {
@@ -920,7 +943,7 @@ pgk_status gemm256_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void*
     }
     const int ntm = ceil_div(M, G2_BM), ntn = ceil_div(N, G2_BN);
     const char* e = getenv("PGK_GEMM256S");          // 0: two full stages, waves in lockstep; default: staggered phases
-    if (!e || atoi(e) != 0) {
+    if (packed || !e || atoi(e) != 0) {
         static bool attr_s = false;
         if (!attr_s) {
             PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_bf16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
@@ -937,9 +960,9 @@ pgk_status gemm256_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void*
                 PGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_bf16_kernel<0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
                 attr_n = true;
             }
-            gemm256s_bf16_kernel<0, 3><<<ntm * ntn3, G2_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn3);
-        } else if (accum_f32) gemm256s_bf16_kernel<1><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn);
-        else gemm256s_bf16_kernel<0><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn);
+            gemm256s_bf16_kernel<0, 3><<<ntm * ntn3, G2_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn3, packed ? 1 : 0);
+        } else if (accum_f32) gemm256s_bf16_kernel<1><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, packed ? 1 : 0);
+        else gemm256s_bf16_kernel<0><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn, packed ? 1 : 0);
         PGK_CHECK_HIP(hipGetLastError());
         return PGK_OK;
     }
@@ -950,7 +973,7 @@ pgk_status gemm256_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void*
 }
 
 // act[M][I] = bf16(silu(A . Wg^T) * (A . Wu^T)), W = fused [2 I, K] gate / up weight (staggered kernel, SwiGLU epilogue)
-pgk_status gemm256_bf16_swiglu_nt(const bf16* A, const bf16* W, bf16* act, int M, int I, int K, hipStream_t st) {
+pgk_status gemm256_bf16_swiglu_nt(const bf16* A, const bf16* W, bf16* act, int M, int I, int K, hipStream_t st, bool packed) {
     PGK_REQUIRE(K % 64 == 0 && K >= 64 && I % 128 == 0, "gemm256 swiglu: K=%d must be a multiple of 64 and I=%d of 128", K, I);
     constexpr size_t LDS = 4 * (size_t)G2_TILE;
     static bool attr_done = false;
@@ -963,9 +986,9 @@ pgk_status gemm256_bf16_swiglu_nt(const bf16* A, const bf16* W, bf16* act, int M
     // 96 act columns per tile (192-column B tiles) when that fills the rounds of the chip better: Qwen3-0.6B at S = 2048 is
     // 8 x 24 = 192 tiles of 128 (three quarters of the CUs, one round) or 8 x 32 = 256 tiles of 96 (all of them)
     if (I % 96 == 0 && 0.75 * ceil_div(ntm * (I / 96), 256) < (double)ceil_div(ntm * ntn, 256) - 0.01) {
-        gemm256s_bf16_kernel<2, 3><<<ntm * (I / 96), G2_THREADS, LDS, st>>>(A, W, nullptr, act, M, I, K, ntm, I / 96);
+        gemm256s_bf16_kernel<2, 3><<<ntm * (I / 96), G2_THREADS, LDS, st>>>(A, W, nullptr, act, M, I, K, ntm, I / 96, packed ? 1 : 0);
     } else {
-        gemm256s_bf16_kernel<2><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, nullptr, act, M, I, K, ntm, ntn);
+        gemm256s_bf16_kernel<2><<<ntm * ntn, G2_THREADS, LDS, st>>>(A, W, nullptr, act, M, I, K, ntm, ntn, packed ? 1 : 0);
     }
     PGK_CHECK_HIP(hipGetLastError());
     return PGK_OK;
@@ -974,7 +997,9 @@ pgk_status gemm256_bf16_swiglu_nt(const bf16* A, const bf16* W, bf16* act, int M
 // 128 x 128 tiles; mode 0: bf16 C (+bias), 1: fp32 C +=, 2: fp32 slabs [splits][M][N] (K split into `splits` runs of whole 64-k steps)
 bool gemm128s_ok(int M, int N, int K) { return M > 128 && K % 64 == 0 && N % 8 == 0 && N >= 8; }
 pgk_status gemm128s_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void* C, int mode, int splits, int M, int N, int K, hipStream_t st,
-                            const QkvHeadArgs* heads) {
+                            const QkvHeadArgs* heads, bool packed) {
+    PGK_REQUIRE(!packed || N % 16 == 0, "gemm128s: the fragment-major weight copy has whole 16-row tiles (N=%d)", N);
+    const int pk = packed ? 1 : 0;
     PGK_REQUIRE(gemm128s_ok(M, N, K) && mode >= 0 && mode <= 4 && splits >= 1 && (splits == 1 || mode == 2), "gemm128s: M=%d N=%d K=%d mode=%d splits=%d", M, N, K, mode, splits);
     PGK_REQUIRE(mode != 4 || N % 64 == 0, "gemm128s: the SwiGLU epilogue needs I=%d to be a multiple of 64", N);
     PGK_REQUIRE(mode != 3 || (heads && N == (heads->hq + 2 * heads->hkv) * 128), "gemm128s: the QKV-heads epilogue needs N=%d = (Hq + 2 Hkv) x 128", N);
@@ -993,11 +1018,11 @@ pgk_status gemm128s_bf16_nt(const bf16* A, const bf16* W, const bf16* bias, void
     const int kps = ceil_div(ceil_div(K, splits), 64) * 64;
     const dim3 grid(ntm * ntn, ceil_div(K, kps));
     PGK_REQUIRE((int)grid.y == splits, "gemm128s: K=%d does not split into %d runs of whole 64-k steps", K, splits);
-    if (mode == 0) gemm128s_bf16_kernel<0><<<grid, G1_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn, kps, hd);
-    else if (mode == 1) gemm128s_bf16_kernel<1><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd);
-    else if (mode == 2) gemm128s_bf16_kernel<2><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd);
-    else if (mode == 3) gemm128s_bf16_kernel<3><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd);
-    else gemm128s_bf16_kernel<4><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd);
+    if (mode == 0) gemm128s_bf16_kernel<0><<<grid, G1_THREADS, LDS, st>>>(A, W, bias, C, M, N, K, ntm, ntn, kps, hd, pk);
+    else if (mode == 1) gemm128s_bf16_kernel<1><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd, pk);
+    else if (mode == 2) gemm128s_bf16_kernel<2><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd, pk);
+    else if (mode == 3) gemm128s_bf16_kernel<3><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd, pk);
+    else gemm128s_bf16_kernel<4><<<grid, G1_THREADS, LDS, st>>>(A, W, nullptr, C, M, N, K, ntm, ntn, kps, hd, pk);
     PGK_CHECK_HIP(hipGetLastError());
     return PGK_OK;
 }

@@ -33,7 +33,9 @@
 
 namespace pgk {
 
-constexpr int SHORT_CTX = 512;   // contexts up to here take the whole-context attention kernels (fused o_proj / direct batch attention)
+constexpr int SHORT_CTX = 512;   // contexts up to here take the whole-context attention kernels (direct batch attention); one sequence: SHORT_CTX_B1
+constexpr int SHORT_CTX_B1 = 384; // a single sequence's fused attention + o_proj kernel walks the context in chunks of 192 rows (AM_CHUNK) in EVERY one of its
+                                  // 256 workgroups: two chunks still beat the split-KV sequence (context 300: 0.616 vs 0.625 ms per step), three do not (400: 0.678 vs 0.627)
 
 pgk_status engine_gemm_nt(const bf16* A, const void* W, const bf16* wscale, bool fp8, void* C, bool accum_f32, int M,
                           int N, int K, hipStream_t st, bool packed = false);      // packed: W = the fragment-major bf16 copy
@@ -2097,7 +2099,8 @@ static pgk_status decode_step(Engine* e, int batch, hipStream_t st, int* launche
 // position (set by pgk_engine_set_state, advanced by every step this library enqueues) stays below SHORT_CTX.  The bound
 // is a speed hint only - both sequences are correct at any context - so a caller that rewrites the device-resident
 // positions behind the library's back loses speed, never correctness; an unknown bound selects the long sequence.
-static bool step_is_short(const Engine* e) { return e->short_path && e->pos_hi >= 0 && e->pos_hi + 1 <= SHORT_CTX; }
+static int short_limit(int batch) { return batch == 1 ? SHORT_CTX_B1 : SHORT_CTX; }
+static bool step_is_short(const Engine* e, int batch) { return e->short_path && e->pos_hi >= 0 && e->pos_hi + 1 <= short_limit(batch); }
 
 static void drop_graphs(Engine* e) {
     for (int i = 0; i < 2; ++i) {
@@ -2582,7 +2585,7 @@ pgk_status pgk_engine_decode_step(pgk_engine eh, int batch, pgk_stream s) {
     Engine* e = (Engine*)eh;
     PGK_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch, "pgk_engine_decode_step: batch %d outside [1,%d]", batch, e->cfg.max_batch);
     int launches = 0;
-    pgk_status r = decode_step(e, batch, resolve_stream(s), &launches, step_is_short(e));
+    pgk_status r = decode_step(e, batch, resolve_stream(s), &launches, step_is_short(e, batch));
     e->launches_per_step = launches;
     if (e->pos_hi >= 0) ++e->pos_hi;
     return r;
@@ -2605,7 +2608,7 @@ pgk_status pgk_engine_profile_step(pgk_engine eh, int batch, int n_iters, float*
         probe.info.clear();
         g_probe = &probe;
         int launches = 0;
-        r = decode_step(e, batch, st, &launches, step_is_short(e));
+        r = decode_step(e, batch, st, &launches, step_is_short(e, batch));
         g_probe = nullptr;
         if (e->pos_hi >= 0) ++e->pos_hi;
         if (r != PGK_OK) break;
@@ -2648,7 +2651,7 @@ pgk_status pgk_engine_timeline(pgk_engine eh, int batch, int warm, uint64_t* h_o
     if (he == hipSuccess) {
         g_probe = &probe;
         int launches = 0;
-        r = decode_step(e, batch, st, &launches, step_is_short(e));
+        r = decode_step(e, batch, st, &launches, step_is_short(e, batch));
         g_probe = nullptr;
         he = hipStreamEndCapture(st, &g);
     }
@@ -2718,7 +2721,7 @@ pgk_status pgk_engine_capture(pgk_engine eh, int batch, pgk_stream s) {
     drop_graphs(e);
     // [0]: the split-KV sequence, needed whenever a context can exceed SHORT_CTX (or the short sequences are switched off);
     // [1]: the short-context sequence.  pgk_engine_replay picks per step.
-    const bool want[2] = {!e->short_path || e->cfg.max_seq_len > SHORT_CTX, e->short_path};
+    const bool want[2] = {!e->short_path || e->cfg.max_seq_len > short_limit(batch), e->short_path};
     for (int v = 0; v < 2; ++v) {
         if (!want[v]) continue;
         PGK_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
@@ -2734,7 +2737,7 @@ pgk_status pgk_engine_capture(pgk_engine eh, int batch, pgk_stream s) {
         e->graph_launches[v] = launches;
     }
     e->graph_batch = batch;
-    e->launches_per_step = e->graph_launches[step_is_short(e) ? 1 : 0];
+    e->launches_per_step = e->graph_launches[step_is_short(e, batch) ? 1 : 0];
     return PGK_OK;
 }
 
@@ -2744,7 +2747,7 @@ pgk_status pgk_engine_replay(pgk_engine eh, int n_steps, pgk_stream s) {
     PGK_REQUIRE(e->exec[0] || e->exec[1], "pgk_engine_replay: no captured graph (call pgk_engine_capture first)");
     hipStream_t st = resolve_stream(s);
     for (int i = 0; i < n_steps; ++i) {
-        int v = (step_is_short(e) && e->exec[1]) ? 1 : 0;
+        int v = (step_is_short(e, e->graph_batch) && e->exec[1]) ? 1 : 0;
         if (!e->exec[v]) v = 1 - v;        // only one sequence was captured (short caches; PGK_FUSED_ATTN=0)
         PGK_CHECK_HIP(hipGraphLaunch(e->exec[v], st));
         e->launches_per_step = e->graph_launches[v];

@@ -404,10 +404,11 @@ pgk_status pgk_engine_profile_step(pgk_engine e, int batch, int n_iters, float* 
  * warm + 1 steps; the engine's own captured graph is untouched. */
 pgk_status pgk_engine_timeline(pgk_engine e, int batch, int warm, uint64_t* h_out, int max_launches, int* n_launches, pgk_stream s);
 /* Capture decode_step(batch) into hipGraphs owned by the engine / replay them.  A step has two launch sequences - the
- * short-context one (contexts <= 512: whole-context attention kernels, 4L+2 launches at batch 1) and the split-KV one
- * (5L+2) - both correct at ANY context; capture records both when the cache can hold more than 512 rows, and replay
- * picks per step by the CONTEXT the step will see, from the positions last given to pgk_engine_set_state plus the steps
- * enqueued since (a host-side bound, a speed hint only).  The reference's fixed cache takes any max_seq_len with one code
+ * short-context one (contexts <= 512, a single sequence <= 384: whole-context attention kernels, 4L+2 launches at batch 1)
+ * and the split-KV one (5L+2), whose slices are cut for a context tier (1024, 2048, ... positions, the cache length) - all
+ * correct at ANY context they cover; capture records the short sequence and one split-KV graph per tier the cache can hold,
+ * and replay picks per step by the CONTEXT the step will see, from the positions last given to pgk_engine_set_state plus
+ * the steps enqueued since (a host-side bound, a speed hint only).  The reference's fixed cache takes any max_seq_len with one code
  * path (src/pygpukit/llm/layers/attention.py:128-146, llm/decode/m1_graph.py:248-325). */
 pgk_status pgk_engine_capture(pgk_engine e, int batch, pgk_stream s);
 pgk_status pgk_engine_replay(pgk_engine e, int n_steps, pgk_stream s);

@@ -513,6 +513,7 @@ struct AttnArgs {
     bf16 *kcache, *vcache;              // this layer: [B][Hkv][max_seq][D]
     const int32_t* positions;
     int hq, hkv, max_seq;
+    int span;             // split path: the positions [0, span) are what the slices cover (<= max_seq: the step's context tier, Engine::step_span)
     float scale;
     // split path
     float* part;          // [B][Hq][nsplit][D+2]
@@ -708,12 +709,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(unsigned long long* tl
         tls.end();
         return;
     }
-    // Slices are cut by ABSOLUTE position (slice s = cache rows [s * chunk, (s + 1) * chunk), chunk from the cache length):
+    // Slices are cut by ABSOLUTE position (slice s = cache rows [s * chunk, (s + 1) * chunk), chunk from the step's context tier a.span <= cache length):
     // no address depends on the context length, so the new token's q/k/v and the slice's first 128 K/V rows are requested
     // before the position is even known (clamped addresses; masked later).  Before, the walk started one scalar and one
     // vector round trip later (position -> slice bounds -> addresses).  Slices beyond the context write empty records.
     constexpr int U1 = 8;
-    const int chunk = decode_chunk_len(a.max_seq, a.nsplit, 4 * PPW);
+    const int chunk = decode_chunk_len(a.span, a.nsplit, 4 * PPW);
     const int c0 = (int)blockIdx.x * chunk;
     NewTokenRaw<G> raw;
     new_token_load<D, G>(a, b, kvh, lane, raw);
@@ -1581,10 +1582,12 @@ struct Engine {
     int32_t* pf_tokens = nullptr;
     int pf_tokens_cap = 0;
     // captured step: [0] the long-context launch sequence, [1] the short-context one (when the engine has both)
-    hipGraph_t graph[2] = {nullptr, nullptr};
-    hipGraphExec_t exec[2] = {nullptr, nullptr};
-    int graph_launches[2] = {0, 0};
+    // captured steps: tier 0 = the short-context sequence (span 0); the others = the split-KV sequence with its slices cut for
+    // contexts up to `span` positions (1024, 2048, ... and the cache length).  pgk_engine_replay picks per step (pick_tier).
+    struct Tier { int span = 0; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int launches = 0; };
+    std::vector<Tier> tiers;
     int graph_batch = 0;
+    int step_span = 0;          // the split-KV slicing of the step being enqueued (launch_attn); 0: the whole cache
     int launches_per_step = 0;
     std::vector<void*> allocs;
 
@@ -1696,6 +1699,8 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, b
     a.kcache = e->kcache + lofs; a.vcache = e->vcache + lofs;
     a.positions = e->positions + b0;
     a.hq = c.num_heads; a.hkv = c.num_kv_heads; a.max_seq = c.max_seq_len;
+    const int span = (e->step_span > 0 && e->step_span < c.max_seq_len) ? e->step_span : c.max_seq_len;
+    a.span = span;
     a.scale = 1.0f / sqrtf((float)D);
     a.part = e->part + (size_t)b0 * c.num_heads * e->nsplit * (D + 2);
     // KV slices per (sequence, kv head): as many as fit ONE wave of workgroups over the chip (a 257th workgroup waits
@@ -1704,8 +1709,10 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, b
     // (batches stream enough KV bytes to want two workgroups per CU: measured 22.1 vs 24.6 us at 8 x 2048 positions)
     int ns = e->cu_count * (m >= 4 ? 2 : 1) / (c.num_kv_heads * m);
     ns = ns < 1 ? 1 : (ns > e->nsplit ? e->nsplit : ns);
-    // slices are cut by absolute position in whole position-group steps: launch only as many as the cache length needs
-    a.nsplit = ceil_div(c.max_seq_len, decode_chunk_len(c.max_seq_len, ns, 4 * (64 / (D / 8))));
+    // slices are cut by absolute position in whole position-group steps: launch only as many as the step's context tier needs
+    // (the tier, not the cache length: with slices of a 4096-row cache a context of 400 kept 3 of 27 slices busy - 0.671 ms per
+    // step against 0.623 on a 1024-row cache)
+    a.nsplit = ceil_div(span, decode_chunk_len(span, ns, 4 * (64 / (D / 8))));
     a.w_o = (const bf16*)L.w_o; a.w_o_scale = (const bf16*)L.s_o; a.H = c.hidden_size; a.rows_per_block = e->oproj_rows;
     a.opart = e->opart ? e->opart + (size_t)b0 * c.num_kv_heads * c.hidden_size : nullptr;
     if (direct) {
@@ -2103,12 +2110,33 @@ static int short_limit(int batch) { return batch == 1 ? SHORT_CTX_B1 : SHORT_CTX
 static bool step_is_short(const Engine* e, int batch) { return e->short_path && e->pos_hi >= 0 && e->pos_hi + 1 <= short_limit(batch); }
 
 static void drop_graphs(Engine* e) {
-    for (int i = 0; i < 2; ++i) {
-        if (e->exec[i]) { (void)hipGraphExecDestroy(e->exec[i]); e->exec[i] = nullptr; }
-        if (e->graph[i]) { (void)hipGraphDestroy(e->graph[i]); e->graph[i] = nullptr; }
-        e->graph_launches[i] = 0;
+    for (auto& t : e->tiers) {
+        if (t.exec) (void)hipGraphExecDestroy(t.exec);
+        if (t.graph) (void)hipGraphDestroy(t.graph);
     }
+    e->tiers.clear();
     e->graph_batch = 0;
+}
+
+// The split-KV slicing a step at the host-side position bound needs: the smallest of 1024, 2048, ... that covers the context, capped at
+// the cache length (an unknown bound: the cache length).
+static int span_for(const Engine* e) {
+    const int cap = e->cfg.max_seq_len;
+    if (e->pos_hi < 0) return cap;
+    int span = 1024;
+    while (span < e->pos_hi + 1 && span < cap) span *= 2;
+    return span < cap ? span : cap;
+}
+
+// The captured step the next replay takes: the short-context sequence while the position bound allows it (and it was captured),
+// otherwise the split-KV tier whose slices cover the context; both kinds are correct at any context they cover.
+static size_t pick_tier(const Engine* e) {
+    const bool has_short = !e->tiers.empty() && e->tiers[0].span == 0;
+    if (has_short && (e->tiers.size() == 1 || step_is_short(e, e->graph_batch))) return 0;
+    const int want = span_for(e);
+    for (size_t i = has_short ? 1 : 0; i < e->tiers.size(); ++i)
+        if (e->tiers[i].span >= want) return i;
+    return e->tiers.size() - 1;
 }
 
 }  // namespace pgk
@@ -2585,6 +2613,7 @@ pgk_status pgk_engine_decode_step(pgk_engine eh, int batch, pgk_stream s) {
     Engine* e = (Engine*)eh;
     PGK_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch, "pgk_engine_decode_step: batch %d outside [1,%d]", batch, e->cfg.max_batch);
     int launches = 0;
+    e->step_span = span_for(e);
     pgk_status r = decode_step(e, batch, resolve_stream(s), &launches, step_is_short(e, batch));
     e->launches_per_step = launches;
     if (e->pos_hi >= 0) ++e->pos_hi;
@@ -2608,6 +2637,7 @@ pgk_status pgk_engine_profile_step(pgk_engine eh, int batch, int n_iters, float*
         probe.info.clear();
         g_probe = &probe;
         int launches = 0;
+        e->step_span = span_for(e);
         r = decode_step(e, batch, st, &launches, step_is_short(e, batch));
         g_probe = nullptr;
         if (e->pos_hi >= 0) ++e->pos_hi;
@@ -2651,6 +2681,7 @@ pgk_status pgk_engine_timeline(pgk_engine eh, int batch, int warm, uint64_t* h_o
     if (he == hipSuccess) {
         g_probe = &probe;
         int launches = 0;
+        e->step_span = span_for(e);
         r = decode_step(e, batch, st, &launches, step_is_short(e, batch));
         g_probe = nullptr;
         he = hipStreamEndCapture(st, &g);
@@ -2719,38 +2750,43 @@ pgk_status pgk_engine_capture(pgk_engine eh, int batch, pgk_stream s) {
     PGK_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch, "pgk_engine_capture: batch %d outside [1,%d]", batch, e->cfg.max_batch);
     hipStream_t st = resolve_stream(s);
     drop_graphs(e);
-    // [0]: the split-KV sequence, needed whenever a context can exceed SHORT_CTX (or the short sequences are switched off);
-    // [1]: the short-context sequence.  pgk_engine_replay picks per step.
-    const bool want[2] = {!e->short_path || e->cfg.max_seq_len > short_limit(batch), e->short_path};
-    for (int v = 0; v < 2; ++v) {
-        if (!want[v]) continue;
+    // tier 0: the short-context sequence; then the split-KV sequence once per context tier (1024, 2048, ... positions and the
+    // cache length) - needed whenever a context can exceed the short limit (or the short sequences are switched off)
+    std::vector<int> spans;
+    if (e->short_path) spans.push_back(0);
+    if (!e->short_path || e->cfg.max_seq_len > short_limit(batch)) {
+        for (int sp = 1024; sp < e->cfg.max_seq_len; sp *= 2) spans.push_back(sp);
+        spans.push_back(e->cfg.max_seq_len);
+    }
+    for (int span : spans) {
         PGK_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
         int launches = 0;
-        pgk_status r = decode_step(e, batch, st, &launches, v == 1);
+        e->step_span = span;
+        pgk_status r = decode_step(e, batch, st, &launches, span == 0);
         hipGraph_t g = nullptr;
         hipError_t he = hipStreamEndCapture(st, &g);
         if (r != PGK_OK) { if (g) (void)hipGraphDestroy(g); drop_graphs(e); return r; }
         if (he != hipSuccess || !g) { drop_graphs(e); return set_error(PGK_ERR_HIP, "pgk_engine_capture: hipStreamEndCapture: %s", hipGetErrorString(he)); }
-        e->graph[v] = g;
-        he = hipGraphInstantiate(&e->exec[v], g, nullptr, nullptr, 0);
+        Engine::Tier t;
+        t.span = span; t.graph = g; t.launches = launches;
+        he = hipGraphInstantiate(&t.exec, g, nullptr, nullptr, 0);
+        e->tiers.push_back(t);      // owned from here on (drop_graphs)
         if (he != hipSuccess) { drop_graphs(e); return set_error(PGK_ERR_HIP, "pgk_engine_capture: hipGraphInstantiate: %s", hipGetErrorString(he)); }
-        e->graph_launches[v] = launches;
     }
     e->graph_batch = batch;
-    e->launches_per_step = e->graph_launches[step_is_short(e, batch) ? 1 : 0];
+    e->launches_per_step = e->tiers[pick_tier(e)].launches;
     return PGK_OK;
 }
 
 pgk_status pgk_engine_replay(pgk_engine eh, int n_steps, pgk_stream s) {
     PGK_REQUIRE(eh, "pgk_engine_replay: null engine");
     Engine* e = (Engine*)eh;
-    PGK_REQUIRE(e->exec[0] || e->exec[1], "pgk_engine_replay: no captured graph (call pgk_engine_capture first)");
+    PGK_REQUIRE(!e->tiers.empty(), "pgk_engine_replay: no captured graph (call pgk_engine_capture first)");
     hipStream_t st = resolve_stream(s);
     for (int i = 0; i < n_steps; ++i) {
-        int v = (step_is_short(e, e->graph_batch) && e->exec[1]) ? 1 : 0;
-        if (!e->exec[v]) v = 1 - v;        // only one sequence was captured (short caches; PGK_FUSED_ATTN=0)
-        PGK_CHECK_HIP(hipGraphLaunch(e->exec[v], st));
-        e->launches_per_step = e->graph_launches[v];
+        const auto& t = e->tiers[pick_tier(e)];
+        PGK_CHECK_HIP(hipGraphLaunch(t.exec, st));
+        e->launches_per_step = t.launches;
         if (e->pos_hi >= 0) ++e->pos_hi;
     }
     return PGK_OK;
@@ -2802,7 +2838,7 @@ pgk_status pgk_engine_set_sampling(pgk_engine eh, float temperature, int top_k, 
     Engine* e = (Engine*)eh;
     hipStream_t st = resolve_stream(s);
     auto drop_graph = [&]() {
-        if (e->exec[0] || e->exec[1]) (void)hipStreamSynchronize(st);
+        if (!e->tiers.empty()) (void)hipStreamSynchronize(st);
         drop_graphs(e);
     };
     if (temperature <= 0.f) {

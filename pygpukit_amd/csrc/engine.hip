@@ -1708,7 +1708,8 @@ static pgk_status launch_attn(Engine* e, int layer, int b0, int m, bool fused, b
     // the workspace was sized for (e->nsplit: ~64 positions per slice at the full cache length)
     // (batches stream enough KV bytes to want two workgroups per CU: measured 22.1 vs 24.6 us at 8 x 2048 positions)
     int ns = e->cu_count * (m >= 4 ? 2 : 1) / (c.num_kv_heads * m);
-    ns = ns < 1 ? 1 : (ns > e->nsplit ? e->nsplit : ns);
+    const int ns_cap = ceil_div(span, 64) < e->nsplit ? ceil_div(span, 64) : e->nsplit;     // ~64 positions per slice at least, by the TIER (not the cache: a tier slices alike on every cache)
+    ns = ns < 1 ? 1 : (ns > ns_cap ? ns_cap : ns);
     // slices are cut by absolute position in whole position-group steps: launch only as many as the step's context tier needs
     // (the tier, not the cache length: with slices of a 4096-row cache a context of 400 kept 3 of 27 slices busy - 0.671 ms per
     // step against 0.623 on a 1024-row cache)

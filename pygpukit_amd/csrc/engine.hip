@@ -728,8 +728,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(unsigned long long* tl
     NewToken<D, G> t;
     new_token_finish<D, G>(a, lane, raw, t);
     tls.phase(1);
-    const int c1 = min(c0 + chunk, ctx);
-    const bool owns_new = (pos < a.max_seq) && (pos >= c0) && (pos < c0 + chunk);
+    // the LAST slice runs to the end of the context wherever that is: the tier (a.span) comes from a host-side bound on the
+    // position, and a caller that moved the device-resident positions past it behind the library's back must lose speed, not rows
+    const bool last_slice = (int)blockIdx.x == a.nsplit - 1;
+    const int c1 = last_slice ? ctx : min(c0 + chunk, ctx);
+    const bool owns_new = (pos < a.max_seq) && (pos >= c0) && (last_slice || pos < c0 + chunk);
     if (owns_new && wid == 0 && lane < LPR && a.g_off == 0) {
         *reinterpret_cast<uint4*>(a.kcache + head_off + (size_t)pos * D + sub * 8) = t.kbits;
         *reinterpret_cast<uint4*>(a.vcache + head_off + (size_t)pos * D + sub * 8) = t.vbits;
